@@ -1,0 +1,278 @@
+"""CPU oracle for the AttModel training hot path.  TEST INFRASTRUCTURE ONLY.
+
+This file restates, in plain torch-CPU ops, the algorithm of the reference's
+hot path.  It is imported only by ``tests/``, ``__graft_entry__.smoke()`` and
+``bench.py``'s ``cpu_baseline`` leg, as the checker / the timed CPU comparator.
+The product path (``asr_amd``) never imports it.
+
+Reference lines followed (paths relative to /root/reference):
+
+* frame stacking ........ utils/utils.py:47-65
+* BLSTM encoder ......... Models/encoder.py:25-35   (torch.nn.LSTM over a packed
+                          batch; third-party arithmetic = the documented PyTorch
+                          LSTM equations, gate order i,f,g,o, b_ih + b_hh)
+* location attention .... Models/attention.py:24-40
+* decoder loop + cell ... Models/decoder.py:36-61, 269-279
+* greedy decode ......... Models/decoder.py:63-130  (beam_width == 1)
+* label smoothing ....... Loss/label_smoothing.py:14-28
+
+Parity pin: ``tests/golden/*.npz`` were produced by importing the reference
+itself (``oracle/make_golden.py``); ``tests/test_oracle_golden.py`` checks this
+restatement against every one of them.
+
+Module/parameter names are kept identical to the reference (31 tensors,
+SURVEY.md section 8b) so a ``state_dict`` moves freely between the reference,
+this oracle and ``asr_amd.Models.AttModel``.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+
+# --------------------------------------------------------------------------
+# utils/utils.py:47-65
+# --------------------------------------------------------------------------
+def frame_stacking(x, x_lengths, stack):
+    if stack == 1:
+        return x, x_lengths
+    n = x.shape[1] // stack
+    return x[:, : n * stack].reshape(x.shape[0], n, -1), x_lengths // stack
+
+
+# --------------------------------------------------------------------------
+# Models/encoder.py:14-35
+# --------------------------------------------------------------------------
+class Encoder(nn.Module):
+    def __init__(self, hp):
+        super().__init__()
+        self.hp = hp
+        self.bi_lstm = nn.LSTM(
+            input_size=hp.lmfb_dim * hp.frame_stacking,
+            hidden_size=hp.num_hidden_nodes_encoder,
+            num_layers=hp.num_encoder_layer,
+            batch_first=True,
+            dropout=hp.encoder_dropout,
+            bidirectional=True,
+        )
+
+    def forward(self, x, lengths):
+        T = x.shape[1]
+        packed = nn.utils.rnn.pack_padded_sequence(
+            x, lengths.cpu(), batch_first=True, enforce_sorted=False)
+        h, _ = self.bi_lstm(packed)
+        hbatch, _ = nn.utils.rnn.pad_packed_sequence(h, batch_first=True, total_length=T)
+        return hbatch
+
+
+def blstm_explicit(x, lengths, lstm: nn.LSTM):
+    """Loop restatement of the packed BLSTM (no dropout), for small shapes.
+
+    Spells out what ``nn.LSTM`` over a packed batch computes: every sequence
+    runs over its own ``lengths[b]`` frames (the reverse direction starts at
+    frame ``lengths[b]-1`` from a zero state) and rows past the length are 0
+    (Models/encoder.py:32-34).  Used by the tests to pin the masking rules the
+    HIP recurrence kernels implement without packing.
+    """
+    B, T, _ = x.shape
+    H = lstm.hidden_size
+    inp = x
+    for layer in range(lstm.num_layers):
+        outs = []
+        for d, sfx in enumerate(("", "_reverse")):
+            w_ih = getattr(lstm, f"weight_ih_l{layer}{sfx}")
+            w_hh = getattr(lstm, f"weight_hh_l{layer}{sfx}")
+            b = getattr(lstm, f"bias_ih_l{layer}{sfx}") + getattr(lstm, f"bias_hh_l{layer}{sfx}")
+            h = x.new_zeros(B, H)
+            c = x.new_zeros(B, H)
+            out = [None] * T
+            order = range(T) if d == 0 else range(T - 1, -1, -1)
+            for t in order:
+                gates = inp[:, t] @ w_ih.t() + h @ w_hh.t() + b
+                i, f, g, o = gates.chunk(4, 1)
+                c_new = torch.sigmoid(f) * c + torch.sigmoid(i) * torch.tanh(g)
+                h_new = torch.sigmoid(o) * torch.tanh(c_new)
+                valid = (t < lengths).to(x.dtype).unsqueeze(1).to(x.device)
+                c = valid * c_new + (1 - valid) * c
+                h = valid * h_new + (1 - valid) * h
+                out[t] = valid * h_new
+            outs.append(torch.stack(out, 1))
+        inp = torch.cat(outs, 2)
+    return inp
+
+
+# --------------------------------------------------------------------------
+# Models/attention.py:6-40
+# --------------------------------------------------------------------------
+class Attention(nn.Module):
+    def __init__(self, hp):
+        super().__init__()
+        hd = hp.num_hidden_nodes_decoder
+        he = hp.num_hidden_nodes_encoder * 2
+        self.L_se = nn.Linear(hd, hd * 2, bias=False)
+        self.L_he = nn.Linear(he, hd * 2)
+        self.L_ee = nn.Linear(hd * 2, 1, bias=False)
+        self.L_fe = nn.Linear(10, hd * 2, bias=False)
+        self.F_conv1d = nn.Conv1d(1, 10, 100, stride=1, padding=50, bias=False)
+
+    def forward(self, s, hbatch, alpha, e_mask):
+        T = hbatch.size(1)
+        f = self.F_conv1d(alpha).transpose(1, 2)[:, :T, :]          # (B,T,10)
+        e = torch.tanh(self.L_se(s).unsqueeze(1) + self.L_he(hbatch) + self.L_fe(f))
+        e = self.L_ee(e)                                            # (B,T,1)
+        w = (e - e.max(1)[0].unsqueeze(1)).exp() * e_mask           # max over ALL T
+        alpha = w / w.sum(dim=1, keepdim=True)
+        g = (alpha * hbatch).sum(dim=1)
+        return g, alpha.transpose(1, 2)
+
+
+def lstm_cell_tanh_form(x, c):
+    """Models/decoder.py:269-279 -- sigmoid written as 0.5*tanh(0.5x)+0.5."""
+    i, f, g, o = x.chunk(4, 1)
+    i = torch.tanh(i * 0.5) * 0.5 + 0.5
+    f = torch.tanh(f * 0.5) * 0.5 + 0.5
+    g = torch.tanh(g)
+    o = torch.tanh(o * 0.5) * 0.5 + 0.5
+    c_next = f * c + i * g
+    return o * torch.tanh(c_next), c_next
+
+
+# --------------------------------------------------------------------------
+# Models/decoder.py:14-61 (+ greedy subset of :63-130)
+# --------------------------------------------------------------------------
+class Decoder(nn.Module):
+    def __init__(self, hp):
+        super().__init__()
+        self.hp = hp
+        hd = hp.num_hidden_nodes_decoder
+        he = hp.num_hidden_nodes_encoder * 2
+        self.hd = hd
+        self.att = Attention(hp)
+        self.L_sy = nn.Linear(hd, hd, bias=False)
+        self.L_gy = nn.Linear(he, hd)
+        self.L_yy = nn.Linear(hd, hp.num_classes)
+        self.L_ys = nn.Embedding(hp.num_classes, hd * 4)
+        self.L_ss = nn.Linear(hd, hd * 4, bias=False)
+        self.L_gs = nn.Linear(he, hd * 4)
+
+    @staticmethod
+    def _mask(hbatch, lengths):
+        B, T, _ = hbatch.shape
+        t = torch.arange(T, device=hbatch.device).unsqueeze(0)
+        return (t < lengths.to(hbatch.device).unsqueeze(1)).to(hbatch.dtype).unsqueeze(2)
+
+    def forward(self, hbatch, lengths, targets):
+        B, T, _ = hbatch.shape
+        L = targets.size(1)
+        e_mask = self._mask(hbatch, lengths)
+        s = hbatch.new_zeros(B, self.hd)
+        c = hbatch.new_zeros(B, self.hd)
+        alpha = hbatch.new_zeros(B, 1, T)
+        ys = []
+        for step in range(L):
+            g, alpha = self.att(s, hbatch, alpha, e_mask)
+            ys.append(self.L_yy(torch.tanh(self.L_gy(g) + self.L_sy(s))))
+            rec = self.L_ys(targets[:, step]) + self.L_ss(s) + self.L_gs(g)
+            s, c = lstm_cell_tanh_form(rec, c)
+        return torch.stack(ys, 1)
+
+    @torch.no_grad()
+    def decode_greedy(self, hbatch, lengths, max_len, eos_id):
+        """beam_width==1 path of Models/decoder.py:63-130 (batch 1).
+
+        Returns (result, raw): ``result`` is what the reference returns (the
+        sequence if it ended in eos, else []), ``raw`` the tokens emitted."""
+        B, T, _ = hbatch.shape
+        e_mask = self._mask(hbatch, lengths)
+        s = hbatch.new_zeros(B, self.hd)
+        c = hbatch.new_zeros(B, self.hd)
+        alpha = hbatch.new_zeros(B, 1, T)
+        seq = []
+        for _ in range(max_len):
+            g, alpha = self.att(s, hbatch, alpha, e_mask)
+            y = F.log_softmax(self.L_yy(torch.tanh(self.L_gy(g) + self.L_sy(s))), dim=1)
+            best = y.argmax(1)
+            seq.append(int(best[0]))
+            rec = self.L_ys(best) + self.L_ss(s) + self.L_gs(g)
+            s, c = lstm_cell_tanh_form(rec, c)
+            if seq[-1] == eos_id:
+                return list(seq), seq
+        return [], seq
+
+
+class AttModel(nn.Module):
+    """Models/AttModel.py:10-39, BLSTM branch."""
+
+    def __init__(self, hp):
+        super().__init__()
+        self.hp = hp
+        self.encoder = Encoder(hp)
+        self.decoder = Decoder(hp)
+
+    def forward(self, x, lengths, targets, src_pos=None):
+        return self.decoder(self.encoder(x, lengths), lengths, targets)
+
+    def decode(self, x, lengths, model_lm=None, src_pos=None):
+        with torch.no_grad():
+            hbatch = self.encoder(x, lengths)
+            return self.decoder.decode_greedy(
+                hbatch, lengths, self.hp.max_decoder_seq_len, self.hp.eos_id)[0]
+
+
+# --------------------------------------------------------------------------
+# Loss/label_smoothing.py:14-28
+# --------------------------------------------------------------------------
+def label_smoothing_loss(predicted_label, target, text_lengths, T_norm=True, B_norm=False, eps=0.1):
+    """Dense restatement (same op sequence as the reference, minus ``.cuda()``)."""
+    B, L, V = predicted_label.shape
+    logp = F.log_softmax(predicted_label, dim=2)
+    q = torch.zeros(B * L, V, dtype=logp.dtype, device=logp.device).scatter(1, target.reshape(-1, 1), 1)
+    q = (q * (1 - eps) + (1 - q) * eps / (V - 1)).view(B, L, V)
+    loss = 0.0
+    for i, t in enumerate(text_lengths.tolist()):
+        term = -(q[i, :t] * logp[i, :t]).sum()
+        loss = loss + (term / t if T_norm else term)
+    if B_norm:
+        loss = loss / B
+    return loss
+
+
+def label_smoothing_loss_closed_form(z, target, text_lengths, T_norm=True, B_norm=False, eps=0.1):
+    """Row-wise closed form of the same loss and its gradient (what the HIP kernel does).
+
+    loss_row = -(1-eps) lp_y - eps/(V-1) (sum_v z_v - V lse - lp_y)
+    dz       = w_row (softmax(z) - q),   w_row = 1/t_i (T_norm) for t < t_i else 0
+    """
+    B, L, V = z.shape
+    lse = torch.logsumexp(z, dim=2)
+    zy = z.gather(2, target.unsqueeze(2)).squeeze(2)
+    lpy = zy - lse
+    off = eps / (V - 1)
+    row = -(1 - eps) * lpy - off * (z.sum(2) - V * lse - lpy)
+    steps = torch.arange(L, device=z.device).unsqueeze(0)
+    tl = text_lengths.to(z.device).unsqueeze(1)
+    w = (steps < tl).to(z.dtype)
+    if T_norm:
+        w = w / tl.to(z.dtype)
+    if B_norm:
+        w = w / B
+    loss = (row * w).sum()
+    q = torch.full_like(z, off).scatter(2, target.unsqueeze(2), 1 - eps)
+    dz = w.unsqueeze(2) * (torch.softmax(z, 2) - q)
+    return loss, dz
+
+
+def make_hp(**kw):
+    """hp attribute bag with the template defaults (configs/hparams_template.py,
+    utils/utils.py:199-220) for the attributes the hot path reads."""
+    import types
+    d = dict(lmfb_dim=80, frame_stacking=3, num_hidden_nodes=320, num_encoder_layer=5,
+             encoder_dropout=0.2, encoder_type=None, decoder_type='Attention',
+             num_classes=1000, eos_id=1, T_norm=True, B_norm=False, beam_width=1,
+             max_decoder_seq_len=200, score_func='log_softmax', clip=5.0, accum_grad=1,
+             lr=1e-3, batch_size=32)
+    d.update(kw)
+    d.setdefault('num_hidden_nodes_encoder', d['num_hidden_nodes'])
+    d.setdefault('num_hidden_nodes_decoder', d['num_hidden_nodes'])
+    return types.SimpleNamespace(**d)

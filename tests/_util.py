@@ -1,0 +1,44 @@
+"""Shared helpers for the tests: golden-fixture loading and error metrics."""
+import ast
+import glob
+import os
+import types
+
+import numpy as np
+import torch
+
+GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+CASES = sorted(os.path.splitext(os.path.basename(p))[0]
+               for p in glob.glob(os.path.join(GOLDEN_DIR, "*.npz")))
+
+
+def load_case(name):
+    z = np.load(os.path.join(GOLDEN_DIR, name + ".npz"), allow_pickle=False)
+    hp = types.SimpleNamespace(**dict(ast.literal_eval(str(z["meta_hp"]))))
+    return z, hp
+
+
+def params_of(z, dtype=torch.float32):
+    return {k[len("param."):]: torch.from_numpy(z[k]).to(dtype)
+            for k in z.files if k.startswith("param.")}
+
+
+def rel_err(a, b):
+    """max |a-b| / max |b|  (scale-relative, the metric the north star states)."""
+    a = torch.as_tensor(a, dtype=torch.float64)
+    b = torch.as_tensor(b, dtype=torch.float64)
+    den = float(b.abs().max())
+    if den == 0.0:
+        return float((a - b).abs().max())
+    return float((a - b).abs().max()) / den
+
+
+def greedy_raw_from_table(table):
+    """Reconstruct the raw argmax sequence from the eos-swept table of results
+    (row e = what decode() returned with eos_id = e; -1 padded)."""
+    best = []
+    for row in table:
+        r = [int(v) for v in row if v >= 0]
+        if len(r) > len(best):
+            best = r
+    return best

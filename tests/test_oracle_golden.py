@@ -1,0 +1,88 @@
+"""CPU: the oracle restatement vs the golden vectors produced by the reference."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import ref_model as R
+from tests._util import CASES, load_case, params_of, rel_err, greedy_raw_from_table
+
+
+@pytest.mark.parametrize("name", CASES)
+@pytest.mark.parametrize("tag,dtype,tol", [("f32", torch.float32, 2e-5), ("f64", torch.float64, 1e-10)])
+def test_forward_backward_matches_reference(name, tag, dtype, tol):
+    z, hp = load_case(name)
+    m = R.AttModel(hp).to(dtype)
+    m.load_state_dict(params_of(z, dtype))
+    m.train()
+    x = torch.from_numpy(z["x"]).to(dtype).requires_grad_(True)
+    lengths = torch.from_numpy(z["lengths"])
+    targets = torch.from_numpy(z["targets"])
+    tl = torch.from_numpy(z["text_lengths"])
+    y = m(x, lengths, targets)
+    loss = R.label_smoothing_loss(y, targets, tl, hp.T_norm, hp.B_norm)
+    loss.backward()
+    assert rel_err(y.detach(), z[f"{tag}.youtput"]) < tol
+    assert abs(float(loss) - float(z[f"{tag}.loss"])) / abs(float(z[f"{tag}.loss"])) < tol
+    assert rel_err(x.grad, z[f"{tag}.dx"]) < 50 * tol
+    for k, p in m.named_parameters():
+        assert rel_err(p.grad, z[f"{tag}.grad.{k}"]) < 50 * tol, k
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_state_dict_keys_identical(name):
+    z, hp = load_case(name)
+    m = R.AttModel(hp)
+    want = sorted(k[len("param."):] for k in z.files if k.startswith("param."))
+    assert sorted(m.state_dict().keys()) == want
+    assert len(want) == 4 * 2 * hp.num_encoder_layer + 15
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_closed_form_loss_and_grad(name):
+    z, hp = load_case(name)
+    y = torch.from_numpy(z["f64.youtput"]).requires_grad_(True)
+    targets = torch.from_numpy(z["targets"])
+    tl = torch.from_numpy(z["text_lengths"])
+    dense = R.label_smoothing_loss(y, targets, tl, hp.T_norm, hp.B_norm)
+    dense.backward()
+    loss, dz = R.label_smoothing_loss_closed_form(y.detach(), targets, tl, hp.T_norm, hp.B_norm)
+    assert abs(float(loss) - float(z["f64.loss"])) < 1e-10 * abs(float(z["f64.loss"]))
+    assert rel_err(dz, y.grad) < 1e-10
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_explicit_blstm_equals_packed(name):
+    z, hp = load_case(name)
+    m = R.AttModel(hp).double()
+    m.load_state_dict(params_of(z, torch.float64))
+    x = torch.from_numpy(z["x"]).double()
+    lengths = torch.from_numpy(z["lengths"])
+    with torch.no_grad():
+        a = m.encoder(x, lengths)
+        b = R.blstm_explicit(x, lengths, m.encoder.bi_lstm)
+    assert rel_err(b, a) < 1e-12
+    for i, n in enumerate(lengths.tolist()):
+        assert float(a[i, n:].abs().max()) == 0.0 if n < x.shape[1] else True
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_greedy_tokens(name):
+    z, hp = load_case(name)
+    m = R.AttModel(hp)
+    m.load_state_dict(params_of(z))
+    m.eval()
+    x = torch.from_numpy(z["x"])
+    lengths = torch.from_numpy(z["lengths"])
+    max_len = int(z["greedy.max_len"])
+    for utt in range(2):
+        if f"greedy.utt{utt}" not in z.files:
+            continue
+        table = z[f"greedy.utt{utt}"]
+        hb = m.encoder(x[utt:utt + 1], lengths[utt:utt + 1])
+        _, raw = m.decoder.decode_greedy(hb, lengths[utt:utt + 1], max_len, eos_id=-1)
+        assert len(raw) == max_len
+        for eos in range(hp.num_classes):
+            want = [int(v) for v in table[eos] if v >= 0]
+            got = raw[:raw.index(eos) + 1] if eos in raw else []
+            assert got == want, (utt, eos)
+        assert greedy_raw_from_table(table) == raw[:len(greedy_raw_from_table(table))]
