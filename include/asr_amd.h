@@ -1,0 +1,212 @@
+/*
+ * asr_amd.h -- C ABI of libasr_amd.so: the MI355X (gfx950) kernels behind the
+ * AttModel training hot path of syoamakase/ASR.
+ *
+ * The reference has no FFI of its own: its seam is the nn.Module / autograd
+ * contract.  Every entry point below therefore cites
+ * the reference *Python* lines whose arithmetic it replaces; the Python
+ * mirror in asr_amd/Models and asr_amd/Loss binds them through ctypes
+ * (INTEGRATION.md shows the stub).
+ *
+ * Conventions
+ *   - plain pointers + sizes only; all pointers are DEVICE pointers unless
+ *     the name ends in _host.  float = IEEE fp32, lengths/targets = int64.
+ *   - the library never allocates or frees device memory; callers pass
+ *     outputs, saved activations and workspaces.  Kernels are enqueued on
+ *     `stream` (a hipStream_t passed as void*) and the call returns without
+ *     synchronising.
+ *   - return 0 on success, a negative code on error; asr_last_error() gives
+ *     the message (thread-local).  Nothing throws across the ABI.
+ */
+#ifndef ASR_AMD_H
+#define ASR_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ASR_OK 0
+#define ASR_ERR_ARG (-1)
+#define ASR_ERR_HIP (-2)
+#define ASR_ERR_WORKSPACE (-3)
+
+int asr_version(void);
+const char *asr_last_error(void);
+
+/* ------------------------------------------------------------------ loss --
+ * Replaces Loss/label_smoothing.py:14-28 (log_softmax + dense smoothed
+ * one-hot + per-utterance python loop) and its autograd backward.
+ *   logits   (B,L,V) f32        targets (B,L) i64       text_lengths (B) i64
+ *   row_loss (B*L)   f32 scratch: weighted per-row loss
+ *   loss     (1)     f32 out
+ *   dlogits  (B,L,V) f32 out: d loss / d logits (rows past text_length = 0);
+ *            may be NULL (forward only)
+ */
+int asr_ls_ce_fwd_bwd(const float *logits, const int64_t *targets, const int64_t *text_lengths,
+                      int B, int L, int V, float eps, int T_norm, int B_norm,
+                      float *row_loss, float *loss, float *dlogits, void *stream);
+
+/* ------------------------------------------------------------------ gemm --
+ * fp32 MFMA GEMM used for every hoisted matrix product of the path:
+ * the per-layer LSTM input projections and their gradients (the GEMMs inside
+ * torch.nn.LSTM, Models/encoder.py:25-33), L_he(hbatch) (Models/attention.py:30,
+ * hoisted out of the decoder loop), L_yy (Models/decoder.py:55) and the
+ * weight gradients of all decoder Linear layers.
+ *
+ *   C[m,n] (+)= alpha * sum_k A(m,k) * B(n,k)  (+ bias1[n] + bias2[n])
+ *
+ * a_mode 0: A(m,k) at A[rowoff_a(m) + k]      (k contiguous)
+ * a_mode 1: A(m,k) at A[rowoff_a(k) + m]      (m contiguous, "A transposed")
+ * b_mode 0: B(n,k) at B[rowoff_b(n) + k]      (k contiguous, weight[n][k])
+ * b_mode 1: B(n,k) at B[rowoff_b(k) + n]      (n contiguous)
+ * C(m,n)    at C[rowoff_c(m) + n]
+ * rowoff_x(i) = (i / x_d) * x_s1 + (i % x_d) * x_s0   (two-level row stride, in
+ * elements; lets time-major and batch-major activations share one kernel).
+ * nbatch > 1 runs independent problems at pointer strides batch_{a,b,c}.
+ * splitk > 1 splits K over blocks and accumulates with float atomics: C must
+ * then hold the initial value (accumulate is implied).
+ */
+typedef struct {
+    const float *A, *B;
+    float *C;
+    int M, N, K;
+    int a_mode, b_mode;
+    int64_t a_s0, a_s1; int a_d;
+    int64_t b_s0, b_s1; int b_d;
+    int64_t c_s0, c_s1; int c_d;
+    const float *bias1, *bias2;
+    float alpha;
+    int accumulate;
+    int splitk;
+    int nbatch;
+    int64_t batch_a, batch_b, batch_c;
+} asr_gemm_desc;
+
+int asr_sgemm(const asr_gemm_desc *d, void *stream);
+
+/* small helpers used by the backward passes (bias gradients, layouts) */
+/* out[n] (+)= sum_m A[rowoff(m) + n]; accumulate != 0 keeps the old value */
+int asr_colsum(const float *A, int M, int N, int64_t s0, int64_t s1, int d,
+               float *out, int accumulate, void *stream);
+/* out[c*R + r] = in[r*C + c], nbatch matrices back to back */
+int asr_transpose(const float *in, float *out, int R, int C, int nbatch, void *stream);
+/* table[idx[i]][:] += src[i][:]  (embedding gradient, Models/decoder.py:57 L_ys) */
+int asr_scatter_add_rows(const float *src, const int64_t *idx, int n_rows, int width,
+                         int64_t src_stride, float *table, void *stream);
+
+/* ----------------------------------------------------------------- BLSTM --
+ * One bidirectional LSTM layer over a ragged batch WITHOUT packing: the
+ * recurrence of torch.nn.LSTM as called by Models/encoder.py:32-34
+ * (pack_padded_sequence(enforce_sorted=False) -> LSTM -> pad_packed_sequence).
+ * Gate order i,f,g,o.  Sequence b runs over lengths[b] frames; the reverse
+ * direction starts at frame lengths[b]-1 from a zero state; output rows at
+ * t >= lengths[b] are exactly 0.
+ *
+ * Layouts (time-major inside the encoder):
+ *   G     [T][B][2][4H] in : x_t W_ih^T + b_ih + b_hh for dir 0 / dir 1
+ *                      out: activated gates (saved for backward)
+ *   Cs    [T][B][2][H]  out: cell state c_t (0 at padded positions)
+ *   Hout  element (t,b,dir*H+j) at t*ho_t + b*ho_b + dir*H + j   (2H wide rows)
+ *   W_hh  [2][4H][H]   (dir 0 = weight_hh_l{k}, dir 1 = weight_hh_l{k}_reverse)
+ *   lengths (B) int32 on device
+ */
+int asr_blstm_fwd(const float *W_hh, float *G, float *Cs, float *Hout,
+                  int64_t ho_t, int64_t ho_b, const int32_t *lengths,
+                  int T, int B, int H, void *stream);
+
+/* Backward of the recurrence.
+ *   W_hhT [2][H][4H]   transposed recurrent weights (asr_transpose)
+ *   G     in: activated gates; out: d loss / d pre-activation gates (0 at padding)
+ *   dHout upstream gradient, element (t,b,dir*H+j) at t*dho_t + b*dho_b + dir*H + j
+ *   dc_ws [2][B][H] scratch
+ * The weight/input gradients are plain GEMMs over G afterwards (asr_sgemm).
+ */
+int asr_blstm_bwd(const float *W_hhT, float *G, const float *Cs, const float *dHout,
+                  int64_t dho_t, int64_t dho_b, const int32_t *lengths,
+                  float *dc_ws, int T, int B, int H, void *stream);
+
+/* inverted dropout between encoder layers (nn.LSTM dropout=, Models/encoder.py:26):
+ * y = x * mask / (1-p), mask ~ Bernoulli(1-p) from a counter-based hash of
+ * (seed, element index); mask (uint8) is saved.  Backward: dx = dy * mask/(1-p). */
+int asr_dropout_fwd(const float *x, float *y, uint8_t *mask, int64_t n, float p,
+                    uint64_t seed, void *stream);
+int asr_dropout_bwd(const float *dy, const uint8_t *mask, float *dx, int64_t n, float p,
+                    void *stream);
+
+/* ------------------------------------------------- attention decoder loop --
+ * Replaces the L-step teacher-forced loop Models/decoder.py:52-60 with
+ * Models/attention.py:24-40 and Models/decoder.py:269-279 inside it, and the
+ * autograd graph PyTorch would record for it.
+ *
+ * Dimensions: B batch, T frames, E encoder width (2*H_enc), Hd decoder width,
+ * A = 2*Hd attention width, L label steps.  NC=10 conv channels, KW=100 taps.
+ */
+typedef struct {
+    int B, T, E, Hd, L, V;
+    /* inputs */
+    const float *hbatch;      /* (B,T,E) */
+    const float *PH;          /* (B,T,A) = L_he(hbatch), hoisted (asr_sgemm) */
+    const int32_t *lengths;   /* (B) */
+    const int64_t *targets;   /* (B,L) */
+    /* parameters, reference layouts */
+    const float *W_se;        /* (A,Hd)   att.L_se.weight */
+    const float *w_ee;        /* (A)      att.L_ee.weight */
+    const float *W_fe;        /* (A,10)   att.L_fe.weight */
+    const float *conv_w;      /* (10,100) att.F_conv1d.weight */
+    const float *W_sy;        /* (Hd,Hd)  */
+    const float *W_gy;        /* (Hd,E)   */
+    const float *b_gy;        /* (Hd)     */
+    const float *Emb;         /* (V,4Hd)  L_ys.weight */
+    const float *W_ss;        /* (4Hd,Hd) */
+    const float *W_gs;        /* (4Hd,E)  */
+    const float *b_gs;        /* (4Hd)    */
+    /* saved activations (outputs of fwd, inputs of bwd) */
+    float *S;                 /* (L+1,B,Hd) decoder state, S[0]=0 */
+    float *C;                 /* (L+1,B,Hd) cell state,   C[0]=0 */
+    float *alpha;             /* (L,B,T)   alignments */
+    float *sproj;             /* (L,B,A)   L_se(s) per step */
+    float *g;                 /* (L,B,E)   contexts */
+    float *U;                 /* (B,L,Hd)  tanh(L_gy g + L_sy s): input of the hoisted L_yy GEMM */
+    float *gates;             /* (L,B,4Hd) activated cell gates */
+    /* workspace */
+    float *ws;                /* asr_attdec_ws_floats() floats */
+} asr_attdec_fwd_args;
+
+int64_t asr_attdec_ws_floats(int B, int T, int E, int Hd, int L);
+int asr_attdec_fwd(const asr_attdec_fwd_args *a, void *stream);
+
+typedef struct {
+    asr_attdec_fwd_args f;    /* same tensors as the forward call */
+    /* transposed parameter copies made by the caller (asr_transpose) */
+    const float *W_seT;       /* (Hd,A)   */
+    const float *W_ssT;       /* (Hd,4Hd) */
+    const float *W_syT;       /* (Hd,Hd)  */
+    const float *W_gsT;       /* (E,4Hd)  */
+    const float *W_gyT;       /* (E,Hd)   */
+    /* upstream */
+    const float *dU;          /* (B,L,Hd) = dY @ W_yy (asr_sgemm) */
+    /* per-step gradients saved for the hoisted weight-gradient GEMMs */
+    float *drec;              /* (L,B,4Hd) d loss / d rec_input */
+    float *dyp;               /* (L,B,Hd)  d loss / d (L_gy g + L_sy s) */
+    float *dsp;               /* (L,B,A)   d loss / d L_se(s) */
+    float *dg;                /* (L,B,E)   d loss / d context */
+    float *de;                /* (L,B,T)   d loss / d energy */
+    float *dF;                /* (L,B,T,10) d loss / d conv features */
+    /* outputs */
+    float *dPH;               /* (B,T,A)  */
+    float *dw_ee;             /* (A)      accumulated (caller zeroes) */
+    float *dW_fe;             /* (A,10)   accumulated (caller zeroes) */
+    float *dconv_w;           /* (10,100) accumulated (caller zeroes) */
+    float *ws;                /* asr_attdec_bwd_ws_floats() floats */
+} asr_attdec_bwd_args;
+
+int64_t asr_attdec_bwd_ws_floats(int B, int T, int E, int Hd, int L);
+int asr_attdec_bwd(const asr_attdec_bwd_args *a, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ASR_AMD_H */
