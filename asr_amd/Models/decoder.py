@@ -1,0 +1,212 @@
+"""Location-aware attention decoder on the HIP kernels -- mirror of
+Models/decoder.py:14-61 (+ greedy subset of :63-130) and Models/attention.py:6-40.
+
+Same parameter names as the reference (``att.L_se.weight`` ... ``L_gs.bias``),
+same ``forward(hbatch, lengths, targets) -> youtput (B,L,V)``.  The L-step loop
+and its BPTT run inside libasr_amd.so (asr_attdec_fwd / asr_attdec_bwd); the
+matrix products that are not on the recurrent chain are hoisted into MFMA GEMMs.
+"""
+import ctypes as C
+import math
+
+import torch
+import torch.nn as nn
+
+from .. import _lib, ops
+from .._lib import AttDecBwdArgs, AttDecFwdArgs, check
+from .attention import Attention
+
+NC, KW = 10, 100
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _fill_fwd_args(a, dims, t):
+    a.B, a.T, a.E, a.Hd, a.L, a.V = dims
+    for k, v in t.items():
+        setattr(a, k, v.data_ptr())
+
+
+class _AttDecFunction(torch.autograd.Function):
+    # parameter order (state_dict order of the reference's Decoder)
+    NAMES = ("W_se", "W_he", "b_he", "w_ee", "W_fe", "conv_w",
+             "W_sy", "W_gy", "b_gy", "W_yy", "b_yy", "Emb", "W_ss", "W_gs", "b_gs")
+
+    @staticmethod
+    def forward(ctx, hbatch, lengths_dev, targets, *params):
+        lib = _lib.load()
+        P = dict(zip(_AttDecFunction.NAMES, params))
+        hbatch = hbatch.contiguous()
+        targets = targets.contiguous()
+        B, T, E = hbatch.shape
+        L = targets.shape[1]
+        Hd = P["W_sy"].shape[0]
+        A = 2 * Hd
+        V = P["W_yy"].shape[0]
+        dev = hbatch.device
+        f32 = dict(device=dev, dtype=torch.float32)
+        # hoisted: PH = L_he(hbatch)  (Models/attention.py:30 redoes this every step)
+        PH = torch.empty(B, T, A, **f32)
+        ops.linear_nt(hbatch.view(B * T, E), P["W_he"], PH.view(B * T, A), bias1=P["b_he"])
+        S = torch.empty(L + 1, B, Hd, **f32)
+        Cst = torch.empty(L + 1, B, Hd, **f32)
+        alpha = torch.empty(L, B, T, **f32)
+        sproj = torch.empty(L, B, A, **f32)
+        g = torch.empty(L, B, E, **f32)
+        gates = torch.empty(L, B, 4 * Hd, **f32)
+        Fc = torch.empty(L, B, T, NC, **f32)
+        ws = torch.empty(int(lib.asr_attdec_ws_floats(B, T, E, Hd, L)), **f32)
+        a = AttDecFwdArgs()
+        tensors = dict(hbatch=hbatch, PH=PH, lengths=lengths_dev, targets=targets,
+                       W_se=P["W_se"], w_ee=P["w_ee"], W_fe=P["W_fe"], conv_w=P["conv_w"],
+                       Emb=P["Emb"], W_ss=P["W_ss"], W_gs=P["W_gs"], b_gs=P["b_gs"],
+                       S=S, C=Cst, alpha=alpha, sproj=sproj, g=g, gates=gates, Fc=Fc, ws=ws)
+        _fill_fwd_args(a, (B, T, E, Hd, L, V), tensors)
+        check(lib.asr_attdec_fwd(C.byref(a), _stream()))
+        # hoisted: U = tanh(L_gy g + L_sy s), youtput = L_yy U   (Models/decoder.py:55)
+        U = torch.empty(L, B, Hd, **f32)
+        ops.linear_nt(g.view(L * B, E), P["W_gy"], U.view(L * B, Hd), bias1=P["b_gy"])
+        ops.linear_nt(S[:L].view(L * B, Hd), P["W_sy"], U.view(L * B, Hd), accumulate=True, act=1)
+        Y = torch.empty(B, L, V, **f32)
+        ops.sgemm(U, P["W_yy"], Y, B * L, V, Hd, a_two=(L, B * Hd, Hd), b_stride=Hd, c_stride=V,
+                  bias1=P["b_yy"])
+        ctx.t = tensors
+        ctx.U = U
+        ctx.dims = (B, T, E, Hd, L, V)
+        ctx.P = P
+        return Y
+
+    @staticmethod
+    def backward(ctx, dY):
+        lib = _lib.load()
+        B, T, E, Hd, L, V = ctx.dims
+        A = 2 * Hd
+        P, t, U = ctx.P, ctx.t, ctx.U
+        dev = dY.device
+        f32 = dict(device=dev, dtype=torch.float32)
+        dY = dY.contiguous()
+        S, g, alpha, hbatch = t["S"], t["g"], t["alpha"], t["hbatch"]
+        u_two = (L, B * Hd, Hd)          # row (b*L + l) of youtput  <->  row (l*B + b) of U
+        G = {}
+        # L_yy
+        dW_yy = torch.empty(V, Hd, **f32)
+        sk = ops.pick_splitk(V, Hd, B * L)
+        if sk > 1:
+            dW_yy.zero_()
+        ops.sgemm(dY, U, dW_yy, V, Hd, B * L, a_mode=1, a_stride=V, b_mode=1, b_two=u_two, c_stride=Hd,
+                  splitk=sk)
+        db_yy = torch.empty(V, **f32)
+        ops.colsum(dY.view(B * L, V), db_yy)
+        dU = torch.empty(L, B, Hd, **f32)
+        ops.sgemm(dY, P["W_yy"], dU, B * L, Hd, V, a_stride=V, b_mode=1, b_stride=Hd, c_two=u_two)
+        dyp = ops.mul_dtanh(dU, U)
+        # the loop
+        W_seT = ops.transpose(P["W_se"])
+        W_ssT = ops.transpose(P["W_ss"])
+        W_syT = ops.transpose(P["W_sy"])
+        W_gsT = ops.transpose(P["W_gs"])
+        W_gyT = ops.transpose(P["W_gy"])
+        drec = torch.empty(L, B, 4 * Hd, **f32)
+        dsp = torch.empty(L, B, A, **f32)
+        dg = torch.empty(L, B, E, **f32)
+        de = torch.empty(L, B, T, **f32)
+        dF = torch.empty(L, B, T, NC, **f32)
+        dPH = torch.empty(B, T, A, **f32)
+        dw_ee = torch.empty(1, A, **f32)
+        dW_fe = torch.empty(A, NC, **f32)
+        dconv = torch.empty(NC, 1, KW, **f32)
+        ws = torch.empty(int(lib.asr_attdec_bwd_ws_floats(B, T, E, Hd, L)), **f32)
+        a = AttDecBwdArgs()
+        _fill_fwd_args(a.f, ctx.dims, t)
+        for k, v in dict(W_seT=W_seT, W_ssT=W_ssT, W_syT=W_syT, W_gsT=W_gsT, W_gyT=W_gyT, dyp=dyp, drec=drec,
+                         dsp=dsp, dg=dg, de=de, dF=dF, dPH=dPH, dw_ee=dw_ee, dW_fe=dW_fe, dconv_w=dconv,
+                         ws=ws).items():
+            setattr(a, k, v.data_ptr())
+        check(lib.asr_attdec_bwd(C.byref(a), _stream()))
+        # hoisted weight gradients: (L*B)-row TN GEMMs over the saved per-step tensors
+        S_in = S[:L].view(L * B, Hd)
+        g2, drec2, dyp2, dsp2 = g.view(L * B, E), drec.view(L * B, 4 * Hd), dyp.view(L * B, Hd), dsp.view(L * B, A)
+
+        def tn(a2, b2):
+            out = torch.empty(a2.shape[1], b2.shape[1], **f32)
+            ops.matmul_tn(a2, b2, out)
+            return out
+
+        G["W_gs"] = tn(drec2, g2)
+        G["W_ss"] = tn(drec2, S_in)
+        G["b_gs"] = torch.empty(4 * Hd, **f32)
+        ops.colsum(drec2, G["b_gs"])
+        G["W_gy"] = tn(dyp2, g2)
+        G["W_sy"] = tn(dyp2, S_in)
+        G["b_gy"] = torch.empty(Hd, **f32)
+        ops.colsum(dyp2, G["b_gy"])
+        G["W_se"] = tn(dsp2, S_in)
+        G["Emb"] = torch.empty(V, 4 * Hd, **f32)
+        ops.scatter_rows(drec2, t["targets"].t().contiguous().view(-1), G["Emb"])
+        dPH2 = dPH.view(B * T, A)
+        h2 = hbatch.view(B * T, E)
+        G["W_he"] = tn(dPH2, h2)
+        G["b_he"] = torch.empty(A, **f32)
+        ops.colsum(dPH2, G["b_he"])
+        G["w_ee"], G["W_fe"], G["conv_w"] = dw_ee, dW_fe, dconv
+        G["W_yy"], G["b_yy"] = dW_yy, db_yy
+        # d hbatch = dPH W_he + sum_s alpha_s (x) dg_s   (per utterance: (T x L) @ (L x E))
+        dh = None
+        if ctx.needs_input_grad[0]:
+            dh = torch.empty(B, T, E, **f32)
+            ops.matmul_nn(dPH2, P["W_he"], dh.view(B * T, E))
+            ops.sgemm(alpha, dg, dh, T, E, L, a_mode=1, a_stride=B * T, b_mode=1, b_stride=B * E, c_stride=E,
+                      accumulate=True, nbatch=B, batch_a=T, batch_b=E, batch_c=T * E)
+        ctx.t = ctx.U = None
+        return (dh, None, None) + tuple(G[n] for n in _AttDecFunction.NAMES)
+
+
+class Decoder(nn.Module):
+    def __init__(self, hp):
+        super().__init__()
+        self.hp = hp
+        hd = hp.num_hidden_nodes_decoder
+        he = hp.num_hidden_nodes_encoder * 2
+        self.num_decoder_hidden_nodes = hd
+        self.num_encoder_hidden_nodes = hp.num_hidden_nodes_encoder
+        self.num_classes = hp.num_classes
+        self.att = Attention(hp)
+        # prediction (Models/decoder.py:25-28)
+        self.L_sy = nn.Linear(hd, hd, bias=False)
+        self.L_gy = nn.Linear(he, hd)
+        self.L_yy = nn.Linear(hd, hp.num_classes)
+        # recurrence (Models/decoder.py:30-33)
+        self.L_ys = nn.Embedding(hp.num_classes, hd * 4)
+        self.L_ss = nn.Linear(hd, hd * 4, bias=False)
+        self.L_gs = nn.Linear(he, hd * 4)
+
+    def _params(self):
+        at = self.att
+        return (at.L_se.weight, at.L_he.weight, at.L_he.bias, at.L_ee.weight, at.L_fe.weight,
+                at.F_conv1d.weight, self.L_sy.weight, self.L_gy.weight, self.L_gy.bias, self.L_yy.weight,
+                self.L_yy.bias, self.L_ys.weight, self.L_ss.weight, self.L_gs.weight, self.L_gs.bias)
+
+    def forward(self, hbatch, lengths, targets):
+        if not hbatch.is_cuda:
+            raise RuntimeError("asr_amd.Decoder: input must be on the GPU; the HIP path has no CPU fallback")
+        lengths_dev = lengths.to(device=hbatch.device, dtype=torch.int32)
+        return _AttDecFunction.apply(hbatch, lengths_dev, targets, *self._params())
+
+    @torch.no_grad()
+    def decode(self, hbatch, lengths, model_lm=None):
+        """Greedy search = the beam_width == 1 path of Models/decoder.py:63-130 (batch 1).
+
+        Runs the same per-step kernels as training (teacher forcing with the
+        argmax fed back one step at a time).  Returns the token list if the
+        hypothesis ends in ``hp.eos_id`` within ``hp.max_decoder_seq_len`` steps,
+        else ``[]`` -- exactly what the reference returns.
+        """
+        return self.decode_raw(hbatch, lengths)[0]
+
+    @torch.no_grad()
+    def decode_raw(self, hbatch, lengths):
+        assert hbatch.shape[0] == 1, "greedy decode is batch-1, as in the reference"
+        from .greedy import greedy_decode
+        return greedy_decode(self, hbatch, lengths, self.hp.max_decoder_seq_len, self.hp.eos_id)

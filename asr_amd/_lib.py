@@ -1,0 +1,104 @@
+"""ctypes binding of libasr_amd.so (the C ABI declared in include/asr_amd.h).
+
+The HIP library is the product path: if it is missing or fails to load this
+module raises -- there is no CPU or eager-PyTorch fallback anywhere in
+``asr_amd``.  Build it with ``make`` (or ``__graft_entry__.build()``).
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libasr_amd.so")
+
+c_f = C.c_void_p      # device pointers travel as integers (tensor.data_ptr())
+c_i64 = C.c_int64
+
+
+class GemmDesc(C.Structure):
+    _fields_ = [
+        ("A", c_f), ("B", c_f), ("C", c_f),
+        ("M", C.c_int), ("N", C.c_int), ("K", C.c_int),
+        ("a_mode", C.c_int), ("b_mode", C.c_int),
+        ("a_s0", c_i64), ("a_s1", c_i64), ("a_d", C.c_int),
+        ("b_s0", c_i64), ("b_s1", c_i64), ("b_d", C.c_int),
+        ("c_s0", c_i64), ("c_s1", c_i64), ("c_d", C.c_int),
+        ("bias1", c_f), ("bias2", c_f),
+        ("alpha", C.c_float),
+        ("accumulate", C.c_int),
+        ("act", C.c_int),
+        ("splitk", C.c_int),
+        ("nbatch", C.c_int),
+        ("batch_a", c_i64), ("batch_b", c_i64), ("batch_c", c_i64),
+    ]
+
+
+class AttDecFwdArgs(C.Structure):
+    _fields_ = [
+        ("B", C.c_int), ("T", C.c_int), ("E", C.c_int), ("Hd", C.c_int), ("L", C.c_int), ("V", C.c_int),
+        ("hbatch", c_f), ("PH", c_f), ("lengths", c_f), ("targets", c_f),
+        ("W_se", c_f), ("w_ee", c_f), ("W_fe", c_f), ("conv_w", c_f),
+        ("Emb", c_f), ("W_ss", c_f), ("W_gs", c_f), ("b_gs", c_f),
+        ("S", c_f), ("C", c_f), ("alpha", c_f), ("sproj", c_f), ("g", c_f), ("gates", c_f), ("Fc", c_f),
+        ("ws", c_f),
+    ]
+
+
+class AttDecBwdArgs(C.Structure):
+    _fields_ = [
+        ("f", AttDecFwdArgs),
+        ("W_seT", c_f), ("W_ssT", c_f), ("W_syT", c_f), ("W_gsT", c_f), ("W_gyT", c_f),
+        ("dyp", c_f),
+        ("drec", c_f), ("dsp", c_f), ("dg", c_f), ("de", c_f), ("dF", c_f),
+        ("dPH", c_f), ("dw_ee", c_f), ("dW_fe", c_f), ("dconv_w", c_f),
+        ("ws", c_f),
+    ]
+
+
+# name -> (restype, argtypes); every symbol include/asr_amd.h declares
+SYMBOLS = {
+    "asr_version": (C.c_int, []),
+    "asr_last_error": (C.c_char_p, []),
+    "asr_ls_ce_fwd_bwd": (C.c_int, [c_f, c_f, c_f, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int,
+                                    c_f, c_f, c_f, c_f]),
+    "asr_sgemm": (C.c_int, [C.POINTER(GemmDesc), c_f]),
+    "asr_colsum": (C.c_int, [c_f, C.c_int, C.c_int, c_i64, c_i64, C.c_int, c_f, C.c_int, c_f, c_f]),
+    "asr_colsum_ws_floats": (c_i64, [C.c_int, C.c_int]),
+    "asr_transpose": (C.c_int, [c_f, c_f, C.c_int, C.c_int, C.c_int, c_f]),
+    "asr_scatter_rows": (C.c_int, [c_f, c_f, C.c_int, C.c_int, c_i64, c_f, C.c_int, c_f]),
+    "asr_mul_dtanh": (C.c_int, [c_f, c_f, c_f, c_i64, c_f]),
+    "asr_scale": (C.c_int, [c_f, c_i64, C.c_float, c_f]),
+    "asr_blstm_fwd": (C.c_int, [c_f, c_f, c_f, c_f, c_i64, c_i64, c_f, C.c_int, C.c_int, C.c_int, c_f]),
+    "asr_blstm_bwd": (C.c_int, [c_f, c_f, c_f, c_f, c_i64, c_i64, c_f, c_f, C.c_int, C.c_int, C.c_int, c_f]),
+    "asr_dropout_fwd": (C.c_int, [c_f, c_f, c_f, c_i64, C.c_float, C.c_uint64, c_f]),
+    "asr_dropout_bwd": (C.c_int, [c_f, c_f, c_f, c_i64, C.c_float, c_f]),
+    "asr_attdec_ws_floats": (c_i64, [C.c_int] * 5),
+    "asr_attdec_fwd": (C.c_int, [C.POINTER(AttDecFwdArgs), c_f]),
+    "asr_attdec_greedy": (C.c_int, [C.POINTER(AttDecFwdArgs), c_f, c_f, c_f, c_f, c_f, c_f, c_f]),
+    "asr_attdec_bwd_ws_floats": (c_i64, [C.c_int] * 5),
+    "asr_attdec_bwd": (C.c_int, [C.POINTER(AttDecBwdArgs), c_f]),
+}
+
+_lib = None
+
+
+def load():
+    """Load the library once and bind every symbol; raises if anything is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"asr_amd: {LIB_PATH} not found -- the HIP extension is required (run `make` in the repo root); "
+            "there is no fallback path")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)      # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc):
+    if rc != 0:
+        raise RuntimeError("asr_amd: " + load().asr_last_error().decode("utf-8", "replace") + f" (code {rc})")

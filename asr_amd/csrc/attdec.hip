@@ -1,0 +1,941 @@
+// Teacher-forced location-aware attention decoder: the L-step loop of
+// Models/decoder.py:52-60 with Models/attention.py:24-40 and the LSTM cell of
+// Models/decoder.py:269-279 inside it, and its closed-form backward (BPTT through
+// s, c AND the alignment alpha -- Models/decoder.py:53 does not detach it).
+//
+// What is hoisted out of the loop (host side, asr_sgemm):
+//   PH = L_he(hbatch)                       (the reference redoes it every step)
+//   U  = tanh(L_gy g + L_sy s), Y = L_yy U  (not on the recurrent chain)
+//   all weight gradients, dh = sum_s alpha_s (x) dg_s, dPH W_he.
+//
+// Per step, forward (4 launches):
+//   sproj_s   = S_s W_se^T                                   tile16 MFMA
+//   energy    : F = conv(alpha_{s-1}); e = w_ee . tanh(sproj + PH + F W_fe^T)
+//   ctx       : alpha = masked softmax(e); g = sum_t alpha h
+//   cell      : rec = Emb[y] + S W_ss^T + g W_gs^T + b; LSTM cell   tile16 MFMA
+//
+// The energy kernels put the FRAME on the lane (64 frames per workgroup, the
+// waves split the attention dimension): the sum over a, the conv features and
+// their gradient are then lane-local, and the per-a operands (sproj, w_ee,
+// W_fe) are wave-uniform LDS broadcasts.  PH tiles are staged through LDS with
+// full-line global reads and read back transposed, bank-conflict free.
+// HBM/L3 traffic per step: PH once (energy) + hbatch once (ctx) = 2*B*T*A*4 B.
+#include "tile16.cuh"
+
+#define NCH 10     // conv channels  (Models/attention.py:22)
+#define KW 100     // conv taps
+#define PADW 50    // conv padding
+#define TT 64      // frames per energy workgroup (= lanes)
+#define EW 8       // waves per energy workgroup
+#define ACH (EW * 16)   // attention-dim chunk staged per pass
+#define TSTR (ACH + 1)  // LDS row stride of the staged tile (odd: conflict-free column reads)
+
+// ------------------------------------------------------------------ sproj --
+__global__ __launch_bounds__(256) void sproj_kernel(const float *__restrict__ S_s,
+                                                    const float *__restrict__ W_se,
+                                                    float *__restrict__ sp, int B, int Hd, int A, int vec) {
+    __shared__ float red[4][16][17];
+    const int lane = threadIdx.x & 63, i = lane & 15;
+    const int n0 = blockIdx.x * 16, b0 = blockIdx.y * 16;
+    const float *xrow = (b0 + i) < B ? S_s + (int64_t)(b0 + i) * Hd : nullptr;
+    const float *wrow = (n0 + i) < A ? W_se + (int64_t)(n0 + i) * Hd : nullptr;
+    Tile16Acc acc;
+    tile16_init(acc);
+    tile16_seg(acc, xrow, wrow, Hd, vec != 0);
+    tile16_reduce(acc, red);
+    const int bi = threadIdx.x >> 4, ni = threadIdx.x & 15;
+    if (b0 + bi < B && n0 + ni < A) sp[(int64_t)(b0 + bi) * A + n0 + ni] = tile16_get(red, bi, ni);
+}
+
+// ---------------------------------------------------- shared energy pieces --
+// uni[a][12] = {sproj[a], w_ee[a], W_fe[a][0..9]}  (wave-uniform operands)
+__device__ __forceinline__ void fill_uni(float *uni, const float *__restrict__ sp_b,
+                                         const float *__restrict__ w_ee,
+                                         const float *__restrict__ W_fe, int A) {
+    for (int idx = threadIdx.x; idx < A * 12; idx += blockDim.x) {
+        const int a = idx / 12, c = idx % 12;
+        float v;
+        if (c == 0) v = sp_b ? sp_b[a] : 0.f;
+        else if (c == 1) v = w_ee[a];
+        else v = W_fe[a * NCH + (c - 2)];
+        uni[idx] = v;
+    }
+}
+
+// Stage PH[b][t0 .. t0+63][ac .. ac+ACH) into tile[64][TSTR]; rows >= nrows and
+// columns >= A are zero.  Global reads are whole 512-byte row segments; the four
+// scalar LDS writes of a float4 are rotated so that each write instruction hits
+// distinct banks.
+__device__ __forceinline__ void stage_tile(float *tile, const float *__restrict__ PHb, int t0, int nrows,
+                                           int ac, int A, bool vec) {
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int it = 0; it < (TT * ACH / 4) / (EW * 64); ++it) {
+        const int f = tid + it * (EW * 64);
+        const int row = f / (ACH / 4), c4 = f % (ACH / 4);
+        const int a = ac + c4 * 4;
+        float v[4] = {0.f, 0.f, 0.f, 0.f};
+        if (row < nrows && a < A) {
+            const float *src = PHb + (int64_t)(t0 + row) * A + a;
+            if (vec && a + 3 < A) {
+                const float4 q = ld4(src);
+                v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
+            } else {
+                v[0] = src[0];
+                if (a + 1 < A) v[1] = src[1];
+                if (a + 2 < A) v[2] = src[2];
+                if (a + 3 < A) v[3] = src[3];
+            }
+        }
+        float *dst = tile + row * TSTR + c4 * 4;
+        const int rot = (c4 >> 3) & 3;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int e = (j + rot) & 3;
+            const float val = e == 0 ? v[0] : (e == 1 ? v[1] : (e == 2 ? v[2] : v[3]));
+            dst[e] = val;
+        }
+    }
+}
+
+// dynamic LDS layout of the energy kernels (floats)
+//   uni  [A*12]   (rounded up to 4)
+//   tile [TT*TSTR]
+//   misc [TT*NCH + 64 + ...] per kernel
+__device__ __forceinline__ int round4(int x) { return (x + 3) & ~3; }
+
+// ------------------------------------------------------- forward: energies --
+// grid (ceil(T/TT), B), block EW*64.  Frames t >= lengths[b] are skipped: their
+// energies only enter the reference through the max shift of the softmax
+// (Models/attention.py:33), which cancels in alpha.
+__global__ __launch_bounds__(EW * 64) void energy_fwd_kernel(
+    const float *__restrict__ PH, const float *__restrict__ alpha_prev /* (B,T) or null */,
+    const float *__restrict__ sp /* (B,A) or null */, const float *__restrict__ w_ee,
+    const float *__restrict__ W_fe, const float *__restrict__ conv_w,
+    const int32_t *__restrict__ lengths, float *__restrict__ e_buf, float *__restrict__ Fc_s, int T, int A,
+    int vec) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int b = blockIdx.y, t0 = blockIdx.x * TT;
+    const int len = min(lengths[b], T);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float *uni = smem;
+    float *tile = uni + round4(A * 12);
+    float *Fs = tile + round4(TT * TSTR);         // [TT][NCH]
+    float *aw = Fs + TT * NCH;                    // [TT + KW] alpha window
+    float *cw = aw + round4(TT + KW);             // [NCH*KW]
+    float *red = cw + NCH * KW;                   // [EW][64]
+    float *Fout = Fc_s + ((int64_t)b * T + t0) * NCH;
+    if (t0 >= len) {
+        // still define Fc for the (unused) padded frames of this tile
+        const int n = min(TT, T - t0) * NCH;
+        for (int i = threadIdx.x; i < n; i += blockDim.x) Fout[i] = 0.f;
+        return;
+    }
+    const int nrows = min(TT, len - t0);
+
+    fill_uni(uni, sp ? sp + (int64_t)b * A : nullptr, w_ee, W_fe, A);
+    if (alpha_prev) {
+        for (int i = threadIdx.x; i < TT + KW; i += blockDim.x) {
+            const int t = t0 - PADW + i;
+            aw[i] = (t >= 0 && t < T) ? alpha_prev[(int64_t)b * T + t] : 0.f;
+        }
+        for (int i = threadIdx.x; i < NCH * KW; i += blockDim.x) cw[i] = conv_w[i];
+    }
+    __syncthreads();
+    // conv features: F[t][c] = sum_k cw[c][k] * alpha_prev[t + k - PADW]; waves 0..4 take 2 channels each
+    if (alpha_prev) {
+        if (wave < NCH / 2) {
+            const int c0 = wave * 2;
+            float f0 = 0.f, f1 = 0.f;
+#pragma unroll 4
+            for (int k = 0; k < KW; ++k) {
+                const float av = aw[lane + k];
+                f0 += cw[c0 * KW + k] * av;
+                f1 += cw[(c0 + 1) * KW + k] * av;
+            }
+            Fs[lane * NCH + c0] = f0;
+            Fs[lane * NCH + c0 + 1] = f1;
+        }
+    } else {
+        for (int i = threadIdx.x; i < TT * NCH; i += blockDim.x) Fs[i] = 0.f;
+    }
+    __syncthreads();
+    float F[NCH];
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) F[c] = Fs[lane * NCH + c];
+    {   // save the conv features for the backward (contiguous, coalesced)
+        const int n = min(TT, T - t0) * NCH;
+        for (int i = threadIdx.x; i < n; i += blockDim.x) Fout[i] = Fs[i];
+    }
+
+    const float *PHb = PH + (int64_t)b * T * A;
+    float eacc = 0.f;
+    for (int ac = 0; ac < A; ac += ACH) {
+        __syncthreads();
+        stage_tile(tile, PHb, t0, nrows, ac, A, vec != 0);
+        __syncthreads();
+        const int abase = ac + wave * 16;
+#pragma unroll 4
+        for (int aa = 0; aa < 16; ++aa) {
+            const int a = abase + aa;
+            if (a < A) {  // wave-uniform
+                const float *u = uni + a * 12;
+                float x = tile[lane * TSTR + wave * 16 + aa] + u[0];
+#pragma unroll
+                for (int c = 0; c < NCH; ++c) x += F[c] * u[2 + c];
+                eacc += u[1] * tanh_f(x);
+            }
+        }
+    }
+    red[wave * 64 + lane] = eacc;
+    __syncthreads();
+    if (wave == 0 && lane < nrows) {
+        float e = 0.f;
+#pragma unroll
+        for (int w = 0; w < EW; ++w) e += red[w * 64 + lane];
+        e_buf[(int64_t)b * T + t0 + lane] = e;
+    }
+}
+
+static size_t energy_fwd_smem(int A) {
+    return sizeof(float) * (size_t)(((A * 12 + 3) & ~3) + ((TT * TSTR + 3) & ~3) + TT * NCH +
+                                    ((TT + KW + 3) & ~3) + NCH * KW + EW * 64);
+}
+
+// ------------------------------------------- forward: softmax + context --
+// grid (ceil(E/64), B), block 256, dynamic LDS T floats.
+__global__ __launch_bounds__(256) void ctx_kernel(const float *__restrict__ e_buf,
+                                                  const float *__restrict__ hbatch,
+                                                  const int32_t *__restrict__ lengths,
+                                                  float *__restrict__ alpha_s, float *__restrict__ g_s, int T,
+                                                  int E, int vec) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    __shared__ float sred[4];
+    __shared__ float cred[16][65];
+    float *al = smem;  // [T]
+    const int b = blockIdx.y, tid = threadIdx.x;
+    const int len = min(lengths[b], T);
+    const float *eb = e_buf + (int64_t)b * T;
+    float mx = -INFINITY;
+    for (int t = tid; t < len; t += 256) mx = fmaxf(mx, eb[t]);
+    mx = wave_max(mx);
+    if ((tid & 63) == 0) sred[tid >> 6] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(sred[0], sred[1]), fmaxf(sred[2], sred[3]));
+    __syncthreads();
+    float sum = 0.f;
+    for (int t = tid; t < len; t += 256) {
+        const float p = fast_exp(eb[t] - mx);
+        al[t] = p;
+        sum += p;
+    }
+    sum = wave_sum(sum);
+    if ((tid & 63) == 0) sred[tid >> 6] = sum;
+    __syncthreads();
+    sum = (sred[0] + sred[1]) + (sred[2] + sred[3]);
+    const float inv = 1.0f / sum;
+    for (int t = tid; t < T; t += 256) {
+        const float a = t < len ? al[t] * inv : 0.f;
+        if (t < len) al[t] = a;
+        if (blockIdx.x == 0) alpha_s[(int64_t)b * T + t] = a;
+    }
+    __syncthreads();
+    const float *hb = hbatch + (int64_t)b * T * E;
+    const int e0 = blockIdx.x * 64;
+    if (vec) {
+        const int tg = tid >> 4, l16 = tid & 15;
+        const int e = e0 + l16 * 4;
+        float4 acc = zero4();
+        if (e < E) {
+#pragma unroll 4
+            for (int t = tg; t < len; t += 16) {
+                const float a = al[t];
+                const float4 h = ld4(hb + (int64_t)t * E + e);
+                acc.x += a * h.x; acc.y += a * h.y; acc.z += a * h.z; acc.w += a * h.w;
+            }
+        }
+        cred[tg][l16 * 4 + 0] = acc.x; cred[tg][l16 * 4 + 1] = acc.y;
+        cred[tg][l16 * 4 + 2] = acc.z; cred[tg][l16 * 4 + 3] = acc.w;
+        __syncthreads();
+        if (tid < 64 && e0 + tid < E) {
+            float s = 0.f;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) s += cred[q][tid];
+            g_s[(int64_t)b * E + e0 + tid] = s;
+        }
+    } else {
+        const int tg = tid >> 6, l = tid & 63;
+        const int e = e0 + l;
+        float acc = 0.f;
+        if (e < E)
+            for (int t = tg; t < len; t += 4) acc += al[t] * hb[(int64_t)t * E + e];
+        cred[tg][l] = acc;
+        __syncthreads();
+        if (tid < 64 && e0 + tid < E)
+            g_s[(int64_t)b * E + e0 + tid] = (cred[0][tid] + cred[1][tid]) + (cred[2][tid] + cred[3][tid]);
+    }
+}
+
+// ------------------------------------------------------- forward: LSTM cell --
+// grid (ceil(Hd/4), ceil(B/16)), block 256
+__global__ __launch_bounds__(256) void cell_fwd_kernel(
+    const float *__restrict__ S_s, const float *__restrict__ C_s, const float *__restrict__ g_s,
+    const int64_t *__restrict__ targets, int s, int L, int V, const float *__restrict__ Emb,
+    const float *__restrict__ W_ss, const float *__restrict__ W_gs, const float *__restrict__ b_gs,
+    float *__restrict__ gates_s, float *__restrict__ S_n, float *__restrict__ C_n, int B, int Hd, int E,
+    int vec_s, int vec_g) {
+    __shared__ float red[4][16][17];
+    const int lane = threadIdx.x & 63, i = lane & 15;
+    const int j0 = blockIdx.x * 4, b0 = blockIdx.y * 16;
+    {
+        const int b = b0 + i;
+        const int gate = i >> 2, j = j0 + (i & 3);
+        const int64_t wr = (int64_t)gate * Hd + j;
+        Tile16Acc acc;
+        tile16_init(acc);
+        tile16_seg(acc, b < B ? S_s + (int64_t)b * Hd : nullptr, j < Hd ? W_ss + wr * Hd : nullptr, Hd,
+                   vec_s != 0);
+        tile16_seg(acc, b < B ? g_s + (int64_t)b * E : nullptr, j < Hd ? W_gs + wr * E : nullptr, E,
+                   vec_g != 0);
+        tile16_reduce(acc, red);
+    }
+    const int tid = threadIdx.x;
+    if (tid < 64) {
+        const int bi = tid >> 2, ju = tid & 3;
+        const int b = b0 + bi, j = j0 + ju;
+        if (b < B && j < Hd) {
+            int64_t y = targets[(int64_t)b * L + s];
+            y = y < 0 ? 0 : (y >= V ? V - 1 : y);
+            float pre[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                pre[g] = tile16_get(red, bi, g * 4 + ju) + Emb[y * 4 * Hd + g * Hd + j] + b_gs[g * Hd + j];
+            const float ig = sigmoid_tanh_form(pre[0]), fg = sigmoid_tanh_form(pre[1]);
+            const float gg = tanh_f(pre[2]), og = sigmoid_tanh_form(pre[3]);
+            const float c = fg * C_s[(int64_t)b * Hd + j] + ig * gg;
+            float *gd = gates_s + (int64_t)b * 4 * Hd;
+            gd[0 * Hd + j] = ig; gd[1 * Hd + j] = fg; gd[2 * Hd + j] = gg; gd[3 * Hd + j] = og;
+            C_n[(int64_t)b * Hd + j] = c;
+            S_n[(int64_t)b * Hd + j] = og * tanh_f(c);
+        }
+    }
+}
+
+// ------------------------------------------------ greedy: output + argmax --
+// Batch-1 greedy search (beam_width == 1 path of Models/decoder.py:63-130):
+// u = tanh(L_gy g + L_sy s), logits = L_yy u, token = argmax (log_softmax is
+// monotone, so it does not change the argmax; ties resolve to the lowest index
+// like torch.argmax).  One workgroup; the token is written to tokens[step] and
+// consumed by cell_fwd_kernel of the same step, so no host sync per token.
+__global__ __launch_bounds__(1024) void greedy_out_kernel(
+    const float *__restrict__ S_s, const float *__restrict__ g_s, const float *__restrict__ W_sy,
+    const float *__restrict__ W_gy, const float *__restrict__ b_gy, const float *__restrict__ W_yy,
+    const float *__restrict__ b_yy, int64_t *__restrict__ tokens, int step, int Hd, int E, int V) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    __shared__ float bestv[16];
+    __shared__ int besti[16];
+    float *u = smem;           // [Hd]
+    float *xs = u + Hd;        // [Hd] state, then [E] context
+    float *xg = xs + Hd;
+    const int tid = threadIdx.x;
+    for (int i = tid; i < Hd; i += 1024) xs[i] = S_s[i];
+    for (int i = tid; i < E; i += 1024) xg[i] = g_s[i];
+    __syncthreads();
+    for (int j = tid; j < Hd; j += 1024) {
+        float acc = b_gy[j];
+        const float *wg = W_gy + (int64_t)j * E;
+        for (int k = 0; k < E; ++k) acc += wg[k] * xg[k];
+        const float *wsr = W_sy + (int64_t)j * Hd;
+        for (int k = 0; k < Hd; ++k) acc += wsr[k] * xs[k];
+        u[j] = tanh_f(acc);
+    }
+    __syncthreads();
+    float bv = -INFINITY;
+    int bi = 0x7fffffff;
+    for (int v = tid; v < V; v += 1024) {
+        float acc = b_yy[v];
+        const float *wy = W_yy + (int64_t)v * Hd;
+        for (int k = 0; k < Hd; ++k) acc += wy[k] * u[k];
+        if (acc > bv) { bv = acc; bi = v; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(bv, o, 64);
+        const int oi = __shfl_xor(bi, o, 64);
+        if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+    }
+    if ((tid & 63) == 0) { bestv[tid >> 6] = bv; besti[tid >> 6] = bi; }
+    __syncthreads();
+    if (tid == 0) {
+        for (int w = 1; w < 16; ++w)
+            if (bestv[w] > bv || (bestv[w] == bv && besti[w] < bi)) { bv = bestv[w]; bi = besti[w]; }
+        tokens[step] = bi;
+    }
+}
+
+static bool al16(const void *p) { return (((uintptr_t)p) & 15) == 0; }
+
+extern "C" int64_t asr_attdec_ws_floats(int B, int T, int E, int Hd, int L) {
+    (void)E; (void)Hd; (void)L;
+    return (int64_t)B * T + 64;
+}
+
+struct GreedyParams {
+    const float *W_sy, *W_gy, *b_gy, *W_yy, *b_yy;
+    int64_t *tokens;
+};
+
+static int run_attdec_fwd(const asr_attdec_fwd_args *a, const GreedyParams *gp, void *stream) {
+    ASR_CHECK_ARG(a != nullptr, "attdec_fwd: null args");
+    const int B = a->B, T = a->T, E = a->E, Hd = a->Hd, L = a->L, V = a->V, A = 2 * Hd;
+    ASR_CHECK_ARG(B > 0 && T > 0 && E > 0 && Hd > 0 && L > 0 && V > 0, "attdec_fwd: bad shape");
+    ASR_CHECK_ARG(a->hbatch && a->PH && a->lengths && a->targets && a->W_se && a->w_ee && a->W_fe &&
+                      a->conv_w && a->Emb && a->W_ss && a->W_gs && a->b_gs && a->S && a->C && a->alpha &&
+                      a->sproj && a->g && a->gates && a->Fc && a->ws,
+                  "attdec_fwd: null pointer");
+    hipStream_t st = (hipStream_t)stream;
+    const size_t esm = energy_fwd_smem(A);
+    ASR_CHECK_ARG(esm <= 160 * 1024 && (size_t)T * 4 <= 128 * 1024, "attdec_fwd: T=%d / A=%d exceed the LDS budget", T, A);
+    static thread_local bool attr_set = false;
+    if (!attr_set) {
+        ASR_CHECK_HIP(hipFuncSetAttribute((const void *)energy_fwd_kernel,
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));
+        ASR_CHECK_HIP(hipFuncSetAttribute((const void *)ctx_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                          128 * 1024));
+        attr_set = true;
+    }
+    const int64_t BH = (int64_t)B * Hd, BT = (int64_t)B * T, BA = (int64_t)B * A, BE = (int64_t)B * E;
+    float *e_buf = a->ws;
+    ASR_CHECK_HIP(hipMemsetAsync(a->S, 0, sizeof(float) * BH, st));
+    ASR_CHECK_HIP(hipMemsetAsync(a->C, 0, sizeof(float) * BH, st));
+    ASR_CHECK_HIP(hipMemsetAsync(a->sproj, 0, sizeof(float) * BA, st));
+    const int vecPH = al16(a->PH) && A % 4 == 0;
+    const int vecH = al16(a->hbatch) && E % 4 == 0;
+    const int vecS = al16(a->S) && al16(a->W_se) && al16(a->W_ss) && Hd % 4 == 0;
+    const int vecG = al16(a->g) && al16(a->W_gs) && E % 4 == 0;
+    for (int s = 0; s < L; ++s) {
+        const float *S_s = a->S + s * BH;
+        float *sp_s = a->sproj + s * BA;
+        if (s > 0) {
+            hipLaunchKernelGGL(sproj_kernel, dim3(cdiv(A, 16), cdiv(B, 16)), dim3(256), 0, st, S_s, a->W_se,
+                               sp_s, B, Hd, A, vecS);
+        }
+        hipLaunchKernelGGL(energy_fwd_kernel, dim3(cdiv(T, TT), B), dim3(EW * 64), esm, st, a->PH,
+                           s > 0 ? a->alpha + (s - 1) * BT : (const float *)nullptr,
+                           s > 0 ? (const float *)sp_s : (const float *)nullptr, a->w_ee, a->W_fe, a->conv_w,
+                           a->lengths, e_buf, a->Fc + (int64_t)s * BT * NCH, T, A, vecPH);
+        hipLaunchKernelGGL(ctx_kernel, dim3(cdiv(E, 64), B), dim3(256), sizeof(float) * T, st, e_buf,
+                           a->hbatch, a->lengths, a->alpha + s * BT, a->g + s * BE, T, E, vecH);
+        if (gp) {
+            hipLaunchKernelGGL(greedy_out_kernel, dim3(1), dim3(1024), sizeof(float) * (2 * Hd + E), st, S_s,
+                               (const float *)(a->g + s * BE), gp->W_sy, gp->W_gy, gp->b_gy, gp->W_yy, gp->b_yy,
+                               gp->tokens, s, Hd, E, V);
+        }
+        hipLaunchKernelGGL(cell_fwd_kernel, dim3(cdiv(Hd, 4), cdiv(B, 16)), dim3(256), 0, st, S_s,
+                           a->C + s * BH, a->g + s * BE, a->targets, s, L, V, a->Emb, a->W_ss, a->W_gs,
+                           a->b_gs, a->gates + s * 4 * BH, a->S + (s + 1) * BH, a->C + (s + 1) * BH, B, Hd, E,
+                           vecS, vecG);
+    }
+    ASR_CHECK_LAUNCH("attdec_fwd kernels");
+    return ASR_OK;
+}
+
+extern "C" int asr_attdec_fwd(const asr_attdec_fwd_args *a, void *stream) {
+    return run_attdec_fwd(a, nullptr, stream);
+}
+
+extern "C" int asr_attdec_greedy(const asr_attdec_fwd_args *a, const float *W_sy, const float *W_gy,
+                                 const float *b_gy, const float *W_yy, const float *b_yy, int64_t *tokens,
+                                 void *stream) {
+    ASR_CHECK_ARG(a != nullptr && W_sy && W_gy && b_gy && W_yy && b_yy && tokens, "attdec_greedy: null pointer");
+    ASR_CHECK_ARG(a->B == 1, "attdec_greedy: batch must be 1 (Models/decoder.py:63-130 is batch-1)");
+    ASR_CHECK_ARG((const void *)a->targets == (const void *)tokens,
+                  "attdec_greedy: a->targets must alias the token buffer");
+    ASR_CHECK_ARG(sizeof(float) * (size_t)(2 * a->Hd + a->E) <= 60 * 1024, "attdec_greedy: Hd/E too large");
+    GreedyParams gp{W_sy, W_gy, b_gy, W_yy, b_yy, tokens};
+    return run_attdec_fwd(a, &gp, stream);
+}
+
+// =================================================================== backward ==
+// Per step s = L-1 .. 0 (4 launches):
+//   dscell  : dS_{s+1} = drec_{s+1} W_ss + dyp_{s+1} W_sy + dsp_{s+1} W_se  (tile16),
+//             then the cell backward of step s -> drec_s, dC carry
+//   dg      : dg_s = drec_s W_gs + dyp_s W_gy                                (tile16)
+//   dalpha  : dalpha = h . dg  +  conv^T(dF_{s+1})
+//   energy_bwd : de = alpha (dalpha - <alpha,dalpha>); dpre = de w_ee (1 - th^2);
+//                dsp partials (sum over t), dF = dpre W_fe (lane-local)
+// After the loop: dPH / dW_fe / dw_ee in one pass over PH with the step loop
+// inside (the tanh is recomputed; no read-modify-write of dPH per step), and
+// the conv-filter gradient as a correlation of dF_s with alpha_{s-1}.
+
+// grid (ceil(Hd/16), ceil(B/16)), block 1024
+__global__ __launch_bounds__(1024) void dscell_kernel(
+    int s, int L, const float *__restrict__ drec_n, const float *__restrict__ dyp_n,
+    const float *__restrict__ dsp_part, int64_t part_stride, float *__restrict__ dsp_n,
+    const float *__restrict__ W_ssT, const float *__restrict__ W_syT, const float *__restrict__ W_seT,
+    const float *__restrict__ gates_s, const float *__restrict__ C_s, const float *__restrict__ C_n,
+    const int32_t *__restrict__ lengths, float *__restrict__ dC, float *__restrict__ drec_s, int B, int Hd,
+    int T, int vec) {
+    __shared__ float red[T16_MAXW][16][17];
+    const int lane = threadIdx.x & 63, i = lane & 15;
+    const int j0 = blockIdx.x * 16, b0 = blockIdx.y * 16;
+    const int A = 2 * Hd;
+    const bool has_next = s + 1 < L;
+    if (has_next) {
+        const int b = b0 + i, j = j0 + i;
+        const bool bv = b < B, jv = j < Hd;
+        Tile16Acc acc;
+        tile16_init(acc);
+        tile16_seg(acc, bv ? drec_n + (int64_t)b * 4 * Hd : nullptr, jv ? W_ssT + (int64_t)j * 4 * Hd : nullptr,
+                   4 * Hd, vec != 0);
+        tile16_seg(acc, bv ? dyp_n + (int64_t)b * Hd : nullptr, jv ? W_syT + (int64_t)j * Hd : nullptr, Hd,
+                   vec != 0);
+        int nparts = 1;
+        if (bv) nparts = max(1, (min(lengths[b], T) + TT - 1) / TT);
+        tile16_seg(acc, bv ? dsp_part + (int64_t)b * A : nullptr, jv ? W_seT + (int64_t)j * A : nullptr, A,
+                   vec != 0, nparts, part_stride,
+                   (blockIdx.x == 0 && bv) ? dsp_n + (int64_t)b * A : nullptr);
+        tile16_reduce(acc, red);
+    }
+    const int tid = threadIdx.x;
+    if (tid < 256) {
+        const int bi = tid >> 4, ji = tid & 15;
+        const int b = b0 + bi, j = j0 + ji;
+        if (b < B && j < Hd) {
+            const float dS = has_next ? tile16_get(red, bi, ji) : 0.f;
+            const float *gd = gates_s + (int64_t)b * 4 * Hd;
+            const float ig = gd[j], fg = gd[Hd + j], gg = gd[2 * Hd + j], og = gd[3 * Hd + j];
+            const float cn = C_n[(int64_t)b * Hd + j], cp = C_s[(int64_t)b * Hd + j];
+            const float tc = tanh_f(cn);
+            const float dO = dS * tc;
+            const float dc = dS * og * (1.f - tc * tc) + dC[(int64_t)b * Hd + j];
+            float *dr = drec_s + (int64_t)b * 4 * Hd;
+            dr[j] = dc * gg * ig * (1.f - ig);
+            dr[Hd + j] = dc * cp * fg * (1.f - fg);
+            dr[2 * Hd + j] = dc * ig * (1.f - gg * gg);
+            dr[3 * Hd + j] = dO * og * (1.f - og);
+            dC[(int64_t)b * Hd + j] = dc * fg;
+        }
+    }
+}
+
+// grid (ceil(E/16), ceil(B/16)), block 1024
+__global__ __launch_bounds__(1024) void dg_kernel(const float *__restrict__ drec_s,
+                                                  const float *__restrict__ dyp_s,
+                                                  const float *__restrict__ W_gsT,
+                                                  const float *__restrict__ W_gyT, float *__restrict__ dg_s,
+                                                  int B, int Hd, int E, int vec) {
+    __shared__ float red[T16_MAXW][16][17];
+    const int lane = threadIdx.x & 63, i = lane & 15;
+    const int e0 = blockIdx.x * 16, b0 = blockIdx.y * 16;
+    const int b = b0 + i, e = e0 + i;
+    Tile16Acc acc;
+    tile16_init(acc);
+    tile16_seg(acc, b < B ? drec_s + (int64_t)b * 4 * Hd : nullptr, e < E ? W_gsT + (int64_t)e * 4 * Hd : nullptr,
+               4 * Hd, vec != 0);
+    tile16_seg(acc, b < B ? dyp_s + (int64_t)b * Hd : nullptr, e < E ? W_gyT + (int64_t)e * Hd : nullptr, Hd,
+               vec != 0);
+    tile16_reduce(acc, red);
+    const int tid = threadIdx.x;
+    if (tid < 256) {
+        const int bi = tid >> 4, ei = tid & 15;
+        if (b0 + bi < B && e0 + ei < E) dg_s[(int64_t)(b0 + bi) * E + e0 + ei] = tile16_get(red, bi, ei);
+    }
+}
+
+// dalpha[b][t] = sum_e dg[b][e] h[b][t][e] + sum_{c,k} dF_next[b][t+PADW-k][c] cw[c][k]
+// grid (ceil(T/32), B), block 256 (one wave per frame, 8 frames per wave).
+// dynamic LDS: dgs[E] + dFw[(32+KW-1)][11] + cws[NCH*KW]
+#define DA_TT 32
+__global__ __launch_bounds__(256) void dalpha_kernel(const float *__restrict__ hbatch,
+                                                     const float *__restrict__ dg_s,
+                                                     const float *__restrict__ dF_next /* (B,T,NCH) or null */,
+                                                     const float *__restrict__ conv_w,
+                                                     const int32_t *__restrict__ lengths,
+                                                     float *__restrict__ dalpha, int T, int E, int vec) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int b = blockIdx.y, t0 = blockIdx.x * DA_TT;
+    const int len = min(lengths[b], T);
+    if (t0 >= len) return;
+    float *dgs = smem;                               // [round4(E)]
+    float *dFw = dgs + ((E + 3) & ~3);               // [(DA_TT + KW - 1)][11]
+    float *cws = dFw + (DA_TT + KW - 1) * 11 + 1;    // [NCH*KW]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int i = tid; i < E; i += 256) dgs[i] = dg_s[(int64_t)b * E + i];
+    if (dF_next) {
+        // window rows r = 0 .. DA_TT+KW-2  <->  frame t0 - (KW-1-PADW) + r
+        for (int i = tid; i < (DA_TT + KW - 1) * NCH; i += 256) {
+            const int r = i / NCH, c = i % NCH;
+            const int t = t0 - (KW - 1 - PADW) + r;
+            dFw[r * 11 + c] = (t >= 0 && t < len) ? dF_next[((int64_t)b * T + t) * NCH + c] : 0.f;
+        }
+        for (int i = tid; i < NCH * KW; i += 256) cws[i] = conv_w[i];
+    }
+    __syncthreads();
+    const float *hb = hbatch + (int64_t)b * T * E;
+    for (int tt = wave; tt < DA_TT; tt += 4) {
+        const int t = t0 + tt;
+        if (t >= len) break;  // wave-uniform
+        float acc = 0.f;
+        if (vec) {
+            const float *hr = hb + (int64_t)t * E;
+            for (int e4 = lane; e4 < E / 4; e4 += 64) {
+                const float4 h = ld4(hr + e4 * 4);
+                const float4 d = *reinterpret_cast<const float4 *>(dgs + e4 * 4);
+                acc += h.x * d.x + h.y * d.y + h.z * d.z + h.w * d.w;
+            }
+        } else {
+            for (int e = lane; e < E; e += 64) acc += hb[(int64_t)t * E + e] * dgs[e];
+        }
+        if (dF_next) {
+            // frame of dF touched by tap k: t + PADW - k  ->  window row tt + (KW-1) - k
+            for (int k = lane; k < KW; k += 64) {
+                const float *fr = dFw + (tt + (KW - 1) - k) * 11;
+#pragma unroll
+                for (int c = 0; c < NCH; ++c) acc += fr[c] * cws[c * KW + k];
+            }
+        }
+        acc = wave_sum(acc);
+        if (lane == 0) dalpha[(int64_t)b * T + t] = acc;
+    }
+}
+
+static size_t dalpha_smem(int E) {
+    return sizeof(float) * (size_t)(((E + 3) & ~3) + (DA_TT + KW - 1) * 11 + 1 + NCH * KW);
+}
+
+// grid (ceil(T/TT), B), block EW*64 (lane = frame)
+__global__ __launch_bounds__(EW * 64) void energy_bwd_kernel(
+    const float *__restrict__ PH, const float *__restrict__ alpha_s, const float *__restrict__ dalpha,
+    const float *__restrict__ sp /* (B,A) */, const float *__restrict__ w_ee, const float *__restrict__ W_fe,
+    const float *__restrict__ Fc_s, const int32_t *__restrict__ lengths, float *__restrict__ de_s,
+    float *__restrict__ dF_s, float *__restrict__ dsp_part /* [tile][B][A] */, int B, int T, int A,
+    int vec) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int b = blockIdx.y, t0 = blockIdx.x * TT;
+    const int len = min(lengths[b], T);
+    if (t0 >= len) return;
+    const int nrows = min(TT, len - t0);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float *uni = smem;
+    float *tile = uni + round4(A * 12);
+    float *red = tile + round4(TT * TSTR);   // [EW][64][NCH] (also used for the dot reduction)
+    const int tid = threadIdx.x;
+
+    // <alpha, dalpha> over the valid frames of this utterance
+    float part = 0.f;
+    for (int t = tid; t < len; t += EW * 64) part += alpha_s[(int64_t)b * T + t] * dalpha[(int64_t)b * T + t];
+    part = wave_sum(part);
+    if (lane == 0) red[wave] = part;
+    fill_uni(uni, sp + (int64_t)b * A, w_ee, W_fe, A);
+    __syncthreads();
+    float dot = 0.f;
+#pragma unroll
+    for (int w = 0; w < EW; ++w) dot += red[w];
+    const int t = t0 + lane;
+    float de = 0.f;
+    float F[NCH];
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) F[c] = 0.f;
+    if (lane < nrows) {
+        const float al = alpha_s[(int64_t)b * T + t];
+        de = al * (dalpha[(int64_t)b * T + t] - dot);
+        const float *fp = Fc_s + ((int64_t)b * T + t) * NCH;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) F[c] = fp[c];
+        if (wave == 0) de_s[(int64_t)b * T + t] = de;
+    }
+    float dFa[NCH];
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) dFa[c] = 0.f;
+
+    const float *PHb = PH + (int64_t)b * T * A;
+    float *dsp_out = dsp_part + ((int64_t)blockIdx.x * B + b) * A;
+    for (int ac = 0; ac < A; ac += ACH) {
+        __syncthreads();
+        stage_tile(tile, PHb, t0, nrows, ac, A, vec != 0);
+        __syncthreads();
+        const int abase = ac + wave * 16;
+#pragma unroll 2
+        for (int aa = 0; aa < 16; ++aa) {
+            const int a = abase + aa;
+            if (a < A) {  // wave-uniform
+                const float *u = uni + a * 12;
+                float x = tile[lane * TSTR + wave * 16 + aa] + u[0];
+#pragma unroll
+                for (int c = 0; c < NCH; ++c) x += F[c] * u[2 + c];
+                const float th = tanh_f(x);
+                const float dpre = de * u[1] * (1.f - th * th);
+#pragma unroll
+                for (int c = 0; c < NCH; ++c) dFa[c] += dpre * u[2 + c];
+                const float ssum = wave_sum(dpre);
+                if (lane == 0) dsp_out[a] = ssum;
+            }
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) red[(wave * 64 + lane) * NCH + c] = dFa[c];
+    __syncthreads();
+    // dF[s][b][t0 .. t0+nrows)[c]: contiguous
+    for (int i = tid; i < nrows * NCH; i += EW * 64) {
+        float v = 0.f;
+#pragma unroll
+        for (int w = 0; w < EW; ++w) v += red[w * 64 * NCH + i];
+        dF_s[((int64_t)b * T + t0) * NCH + i] = v;
+    }
+}
+
+static size_t energy_bwd_smem(int A) {
+    return sizeof(float) * (size_t)(((A * 12 + 3) & ~3) + ((TT * TSTR + 3) & ~3) + EW * 64 * NCH);
+}
+
+// ------------------------------------------------- after the loop: dPH etc --
+// grid (ceil(T/64), B, ceil(A/P2_A)), block 256 (4 waves; lane = frame).  Each
+// wave owns 8 attention columns at a time and walks all L steps with them in
+// registers: dPH[t][a] = sum_s de_s[t] w_ee[a] (1 - tanh^2(...)), and the
+// per-(tile,b) partial sums of dW_fe[a][c] and dw_ee[a].
+#define P2_A 128
+#define P2_Q 8
+__global__ __launch_bounds__(256) void phase2_kernel(
+    const float *__restrict__ PH, const float *__restrict__ sproj /* (L,B,A) */,
+    const float *__restrict__ de /* (L,B,T) */, const float *__restrict__ Fc /* (L,B,T,NCH) */,
+    const float *__restrict__ w_ee, const float *__restrict__ W_fe, const int32_t *__restrict__ lengths,
+    float *__restrict__ dPH, float *__restrict__ part /* [tile*B + b][A][11] */, int L, int B, int T, int A) {
+    const int b = blockIdx.y, t0 = blockIdx.x * 64;
+    const int len = min(lengths[b], T);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int t = t0 + lane;
+    const bool tv = t < len;
+    const bool trow = t < T;
+    float *pout = part + ((int64_t)blockIdx.x * B + b) * A * 11;
+    const int a_lo = blockIdx.z * P2_A + wave * (P2_A / 4);
+    for (int aq = 0; aq < P2_A / 4; aq += P2_Q) {
+        const int a0 = a_lo + aq;
+        if (a0 >= A) break;  // wave-uniform
+        float ph[P2_Q], wee[P2_Q], wfe[P2_Q][NCH];
+        float acc_ph[P2_Q], acc_ee[P2_Q], acc_fe[P2_Q][NCH];
+#pragma unroll
+        for (int q = 0; q < P2_Q; ++q) {
+            const int a = a0 + q;
+            const bool av = a < A;
+            ph[q] = (tv && av) ? PH[((int64_t)b * T + t) * A + a] : 0.f;
+            wee[q] = av ? w_ee[a] : 0.f;
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) {
+                wfe[q][c] = av ? W_fe[a * NCH + c] : 0.f;
+                acc_fe[q][c] = 0.f;
+            }
+            acc_ph[q] = 0.f;
+            acc_ee[q] = 0.f;
+        }
+        if (t0 < len) {  // block-uniform
+            for (int s = 0; s < L; ++s) {
+                float dev = 0.f, F[NCH];
+#pragma unroll
+                for (int c = 0; c < NCH; ++c) F[c] = 0.f;
+                if (tv) {
+                    dev = de[((int64_t)s * B + b) * T + t];
+                    const float *fp = Fc + (((int64_t)s * B + b) * T + t) * NCH;
+#pragma unroll
+                    for (int c = 0; c < NCH; ++c) F[c] = fp[c];
+                }
+                const float *sp = sproj + ((int64_t)s * B + b) * A;
+#pragma unroll
+                for (int q = 0; q < P2_Q; ++q) {
+                    const int a = a0 + q;
+                    float x = ph[q] + (a < A ? sp[a] : 0.f);
+#pragma unroll
+                    for (int c = 0; c < NCH; ++c) x += F[c] * wfe[q][c];
+                    const float th = tanh_f(x);
+                    const float dth = dev * (1.f - th * th);
+                    const float dpre = dth * wee[q];
+                    acc_ph[q] += dpre;
+                    acc_ee[q] += dev * th;
+#pragma unroll
+                    for (int c = 0; c < NCH; ++c) acc_fe[q][c] += dpre * F[c];
+                }
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < P2_Q; ++q) {
+            const int a = a0 + q;
+            if (a < A) {  // wave-uniform
+                if (trow) dPH[((int64_t)b * T + t) * A + a] = acc_ph[q];
+                const float se = wave_sum(acc_ee[q]);
+                float sf[NCH];
+#pragma unroll
+                for (int c = 0; c < NCH; ++c) sf[c] = wave_sum(acc_fe[q][c]);
+                if (lane == 0) {
+                    pout[a * 11 + 0] = se;
+#pragma unroll
+                    for (int c = 0; c < NCH; ++c) pout[a * 11 + 1 + c] = sf[c];
+                }
+            }
+        }
+    }
+}
+
+// out[i] = sum_p part[p*n + i]
+__global__ __launch_bounds__(256) void reduce_parts_kernel(const float *__restrict__ part, int nparts,
+                                                           int64_t n, float *__restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float s = 0.f;
+    for (int p = 0; p < nparts; ++p) s += part[(int64_t)p * n + i];
+    out[i] = s;
+}
+
+// split [A][11] sums into dw_ee[A] and dW_fe[A][10]
+__global__ __launch_bounds__(256) void split_fe_kernel(const float *__restrict__ sum11, int A,
+                                                       float *__restrict__ dw_ee, float *__restrict__ dW_fe) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= A * 11) return;
+    const int a = i / 11, c = i % 11;
+    if (c == 0) dw_ee[a] = sum11[i];
+    else dW_fe[a * NCH + c - 1] = sum11[i];
+}
+
+// conv-filter gradient: dcw[c][k] = sum_{s>=1,b,t<len} dF[s][b][t][c] alpha[s-1][b][t+k-PADW]
+// grid ((L-1)*B), block 128: thread k < KW owns tap k for all channels.
+__global__ __launch_bounds__(128) void dconv_kernel(const float *__restrict__ dF, const float *__restrict__ alpha,
+                                                    const int32_t *__restrict__ lengths,
+                                                    float *__restrict__ part /* [(L-1)*B][NCH*KW] */, int B,
+                                                    int T) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int s = 1 + blockIdx.x / B, b = blockIdx.x % B;
+    const int len = min(lengths[b], T);
+    float *aw = smem;                   // [T + KW] : alpha_{s-1}[t - PADW], zero padded
+    float *dFs = aw + ((T + KW + 3) & ~3);   // [len][NCH] (12-float rows)
+    const int tid = threadIdx.x;
+    const float *ap = alpha + ((int64_t)(s - 1) * B + b) * T;
+    for (int i = tid; i < T + KW; i += 128) {
+        const int t = i - PADW;
+        aw[i] = (t >= 0 && t < T) ? ap[t] : 0.f;
+    }
+    const float *fp = dF + ((int64_t)s * B + b) * T * NCH;
+    for (int i = tid; i < len * NCH; i += 128) dFs[(i / NCH) * 12 + (i % NCH)] = fp[i];
+    __syncthreads();
+    if (tid < KW) {
+        float acc[NCH];
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) acc[c] = 0.f;
+        for (int t = 0; t < len; ++t) {
+            const float av = aw[t + tid];
+            const float *f = dFs + t * 12;
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) acc[c] += f[c] * av;
+        }
+        float *po = part + (int64_t)blockIdx.x * NCH * KW;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) po[c * KW + tid] = acc[c];
+    }
+}
+
+static int64_t bwd_ntile(int T) { return cdiv(T, TT); }
+
+extern "C" int64_t asr_attdec_bwd_ws_floats(int B, int T, int E, int Hd, int L) {
+    (void)E;
+    const int64_t A = 2 * Hd, nt = bwd_ntile(T);
+    int64_t n = 0;
+    n += (int64_t)B * T + 64;                    // dalpha
+    n += (int64_t)B * Hd + 64;                   // dC carry
+    n += nt * B * A + 64;                        // dsp partials
+    int64_t post = nt * B * A * 11 + A * 11 + 64;               // phase-2 partials + sums
+    int64_t conv = (int64_t)(L > 1 ? L - 1 : 1) * B * NCH * KW + 64;   // conv partials
+    n += post > conv ? post : conv;
+    return n;
+}
+
+extern "C" int asr_attdec_bwd(const asr_attdec_bwd_args *a, void *stream) {
+    ASR_CHECK_ARG(a != nullptr, "attdec_bwd: null args");
+    const asr_attdec_fwd_args *f = &a->f;
+    const int B = f->B, T = f->T, E = f->E, Hd = f->Hd, L = f->L, A = 2 * Hd;
+    ASR_CHECK_ARG(B > 0 && T > 0 && E > 0 && Hd > 0 && L > 0, "attdec_bwd: bad shape");
+    ASR_CHECK_ARG(f->hbatch && f->PH && f->lengths && f->w_ee && f->W_fe && f->conv_w && f->C && f->alpha &&
+                      f->sproj && f->gates && f->Fc,
+                  "attdec_bwd: null forward tensor");
+    ASR_CHECK_ARG(a->W_seT && a->W_ssT && a->W_syT && a->W_gsT && a->W_gyT && a->dyp && a->drec && a->dsp &&
+                      a->dg && a->de && a->dF && a->dPH && a->dw_ee && a->dW_fe && a->dconv_w && a->ws,
+                  "attdec_bwd: null pointer");
+    hipStream_t st = (hipStream_t)stream;
+    const size_t esm = energy_bwd_smem(A), dsm = dalpha_smem(E);
+    const size_t csm = sizeof(float) * (size_t)(((T + KW + 3) & ~3) + (size_t)T * 12);
+    ASR_CHECK_ARG(esm <= 159 * 1024 && dsm <= 159 * 1024 && csm <= 159 * 1024,
+                  "attdec_bwd: T=%d / A=%d / E=%d exceed the LDS budget", T, A, E);
+    static thread_local bool attr_set = false;
+    if (!attr_set) {
+        ASR_CHECK_HIP(hipFuncSetAttribute((const void *)energy_bwd_kernel,
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024));
+        ASR_CHECK_HIP(hipFuncSetAttribute((const void *)dalpha_kernel,
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024));
+        ASR_CHECK_HIP(hipFuncSetAttribute((const void *)dconv_kernel,
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024));
+        attr_set = true;
+    }
+    const int64_t BH = (int64_t)B * Hd, BT = (int64_t)B * T, BA = (int64_t)B * A, BE = (int64_t)B * E;
+    const int64_t nt = bwd_ntile(T);
+    float *w = a->ws;
+    float *dalpha = w;            w += BT + 64;
+    float *dC = w;                w += BH + 64;
+    float *dsp_part = w;          w += nt * BA + 64;
+    float *post = w;
+    ASR_CHECK_HIP(hipMemsetAsync(dC, 0, sizeof(float) * BH, st));
+    const int vecPH = al16(f->PH) && A % 4 == 0;
+    const int vecH = al16(f->hbatch) && E % 4 == 0;
+    const int vecT = Hd % 4 == 0 && al16(a->drec) && al16(a->dyp) && al16(dsp_part) && al16(a->W_ssT) &&
+                     al16(a->W_syT) && al16(a->W_seT) && al16(a->W_gsT) && al16(a->W_gyT);
+
+    for (int s = L - 1; s >= 0; --s) {
+        const bool has_next = s + 1 < L;
+        hipLaunchKernelGGL(dscell_kernel, dim3(cdiv(Hd, 16), cdiv(B, 16)), dim3(1024), 0, st, s, L,
+                           has_next ? a->drec + (s + 1) * 4 * BH : (const float *)nullptr,
+                           has_next ? a->dyp + (s + 1) * BH : (const float *)nullptr,
+                           (const float *)dsp_part, (int64_t)BA,
+                           has_next ? a->dsp + (s + 1) * BA : (float *)nullptr, a->W_ssT, a->W_syT, a->W_seT,
+                           f->gates + s * 4 * BH, f->C + s * BH, f->C + (s + 1) * BH, f->lengths, dC,
+                           a->drec + s * 4 * BH, B, Hd, T, vecT);
+        hipLaunchKernelGGL(dg_kernel, dim3(cdiv(E, 16), cdiv(B, 16)), dim3(1024), 0, st,
+                           (const float *)(a->drec + s * 4 * BH), a->dyp + s * BH, a->W_gsT, a->W_gyT,
+                           a->dg + s * BE, B, Hd, E, vecT);
+        hipLaunchKernelGGL(dalpha_kernel, dim3(cdiv(T, DA_TT), B), dim3(256), dsm, st, f->hbatch,
+                           (const float *)(a->dg + s * BE),
+                           has_next ? (const float *)(a->dF + (s + 1) * BT * NCH) : (const float *)nullptr,
+                           f->conv_w, f->lengths, dalpha, T, E, vecH);
+        hipLaunchKernelGGL(energy_bwd_kernel, dim3(cdiv(T, TT), B), dim3(EW * 64), esm, st, f->PH,
+                           (const float *)(f->alpha + s * BT), (const float *)dalpha,
+                           (const float *)(f->sproj + s * BA), f->w_ee, f->W_fe,
+                           (const float *)(f->Fc + s * BT * NCH), f->lengths, a->de + s * BT,
+                           a->dF + s * BT * NCH, dsp_part, B, T, A, vecPH);
+    }
+    // dsp_0 (needed for dW_se = sum_s dsp_s^T S_s; S_0 = 0 so only for completeness): reduce the partials
+    {
+        // reuse dscell's summation path is not possible at s = -1; S_0 == 0 makes dsp_0 irrelevant to
+        // every gradient, so it is defined as zero.
+        ASR_CHECK_HIP(hipMemsetAsync(a->dsp, 0, sizeof(float) * BA, st));
+    }
+    // dPH, dW_fe, dw_ee
+    {
+        float *part = post;
+        float *sum11 = post + nt * BA * 11;
+        hipLaunchKernelGGL(phase2_kernel, dim3(nt, B, cdiv(A, P2_A)), dim3(256), 0, st, f->PH,
+                           (const float *)f->sproj, (const float *)a->de, (const float *)f->Fc, f->w_ee,
+                           f->W_fe, f->lengths, a->dPH, part, L, B, T, A);
+        hipLaunchKernelGGL(reduce_parts_kernel, dim3(cdiv((int64_t)A * 11, 256)), dim3(256), 0, st,
+                           (const float *)part, (int)(nt * B), (int64_t)A * 11, sum11);
+        hipLaunchKernelGGL(split_fe_kernel, dim3(cdiv((int64_t)A * 11, 256)), dim3(256), 0, st,
+                           (const float *)sum11, A, a->dw_ee, a->dW_fe);
+    }
+    // conv filter gradient (stream order: runs after phase 2 has finished with `post`)
+    if (L > 1) {
+        float *part = post;
+        hipLaunchKernelGGL(dconv_kernel, dim3((L - 1) * B), dim3(128), csm, st, (const float *)a->dF,
+                           (const float *)f->alpha, f->lengths, part, B, T);
+        hipLaunchKernelGGL(reduce_parts_kernel, dim3(cdiv(NCH * KW, 256)), dim3(256), 0, st,
+                           (const float *)part, (L - 1) * B, (int64_t)NCH * KW, a->dconv_w);
+    } else {
+        ASR_CHECK_HIP(hipMemsetAsync(a->dconv_w, 0, sizeof(float) * NCH * KW, st));
+    }
+    ASR_CHECK_LAUNCH("attdec_bwd kernels");
+    return ASR_OK;
+}

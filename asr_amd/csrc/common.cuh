@@ -39,6 +39,12 @@ void asr_set_error(const char *fmt, ...);
         }                                                                      \
     } while (0)
 
+#define ASR_CHECK(expr)                  \
+    do {                                 \
+        int r__ = (expr);                \
+        if (r__ != ASR_OK) return r__;   \
+    } while (0)
+
 // ------------------------------------------------------------ device math --
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
@@ -51,23 +57,36 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 
-// sigmoid as torch.nn.LSTM computes it (1/(1+exp(-x))), accurate expf
-__device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + expf(-x)); }
+// exp(x) through the hardware 2^x unit (1 ulp) -- x*log2(e) in fp32.
+__device__ __forceinline__ float fast_exp(float x) {
+    return __builtin_amdgcn_exp2f(x * 1.44269504088896340736f);
+}
 
-// tanh with ~1e-7 absolute error: 1 - 2/(exp(2x)+1); saturates cleanly.
+// tanh with ~2e-7 absolute error: 1 - 2/(exp(2|x|)+1); saturates cleanly,
+// short odd series near 0 where the subtraction would cancel.
 __device__ __forceinline__ float tanh_f(float x) {
     float ax = fabsf(x);
-    if (ax < 0.04f) {  // odd Taylor series, avoids cancellation near 0
-        float x2 = x * x;
-        return x * (1.0f + x2 * (-0.33333333f + x2 * (0.13333333f - x2 * 0.053968254f)));
-    }
-    float e = expf(2.0f * ax);
-    float r = 1.0f - 2.0f / (e + 1.0f);
+    float e = __builtin_amdgcn_exp2f(ax * 2.88539008177792681472f);  // exp(2|x|)
+    float r = 1.0f - 2.0f * __builtin_amdgcn_rcpf(e + 1.0f);
+    float x2 = x * x;
+    float s = ax * (1.0f + x2 * (-0.33333333f + x2 * (0.13333333f - x2 * 0.053968254f)));
+    r = ax < 0.04f ? s : r;
     return copysignf(r, x);
 }
+
+// sigmoid as torch.nn.LSTM computes it, 1/(1+exp(-x))
+__device__ __forceinline__ float sigmoid_f(float x) {
+    return 1.0f / (1.0f + fast_exp(-x));
+}
+
+// sigmoid in the tanh form of Models/decoder.py:269-279
+__device__ __forceinline__ float sigmoid_tanh_form(float x) { return 0.5f * tanh_f(0.5f * x) + 0.5f; }
 
 __host__ __device__ __forceinline__ int64_t rowoff2(int64_t i, int d, int64_t s0, int64_t s1) {
     return (i / d) * s1 + (i % d) * s0;
 }
 
 static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+
+__device__ __forceinline__ float4 ld4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
+__device__ __forceinline__ float4 zero4() { return make_float4(0.f, 0.f, 0.f, 0.f); }

@@ -1,0 +1,231 @@
+// Error reporting and the small data-movement helpers of the backward passes.
+#include <stdarg.h>
+#include <string.h>
+
+#include "common.cuh"
+
+static thread_local char g_err[512] = "";
+
+void asr_set_error(const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+extern "C" int asr_version(void) { return 100; }
+extern "C" const char *asr_last_error(void) { return g_err; }
+
+// ---------------------------------------------------------------- colsum --
+// out[n] (+)= sum_m A[rowoff(m) + n].  Two stages so the result is
+// deterministic: each block sums a strip of rows into part[strip][n] (or
+// straight into out when one strip suffices).
+#define CS_ROWS 512
+__global__ __launch_bounds__(256) void colsum_kernel(const float *__restrict__ A, int M, int N,
+                                                     int64_t s0, int64_t s1, int d,
+                                                     float *__restrict__ out, int accumulate,
+                                                     int rows_per_block) {
+    __shared__ float sh[4][64];
+    const int n = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int q = threadIdx.x >> 6;
+    const int m_begin = blockIdx.y * rows_per_block;
+    const int m_end = min(M, m_begin + rows_per_block);
+    float acc = 0.f;
+    if (n < N)
+        for (int m = m_begin + q; m < m_end; m += 4) acc += A[rowoff2(m, d, s0, s1) + n];
+    sh[q][threadIdx.x & 63] = acc;
+    __syncthreads();
+    if (q == 0 && n < N) {
+        float v = (sh[0][threadIdx.x] + sh[1][threadIdx.x]) + (sh[2][threadIdx.x] + sh[3][threadIdx.x]);
+        float *dst = out + (int64_t)blockIdx.y * N + n;
+        if (accumulate) v += *dst;
+        *dst = v;
+    }
+}
+
+extern "C" int asr_colsum(const float *A, int M, int N, int64_t s0, int64_t s1, int d, float *out,
+                          int accumulate, float *part, void *stream) {
+    ASR_CHECK_ARG(A && out, "colsum: null pointer");
+    ASR_CHECK_ARG(M >= 0 && N > 0, "colsum: bad shape");
+    if (d <= 0) d = 0x7fffffff;
+    hipStream_t st = (hipStream_t)stream;
+    const int strips = cdiv(M > 0 ? M : 1, CS_ROWS);
+    if (strips == 1 || part == nullptr) {
+        hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(N, 64), 1), dim3(256), 0, st, A, M, N, s0, s1, d, out,
+                           accumulate, M > 0 ? M : 1);
+    } else {
+        hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(N, 64), strips), dim3(256), 0, st, A, M, N, s0, s1, d,
+                           part, 0, CS_ROWS);
+        hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(N, 64), 1), dim3(256), 0, st, part, strips, N,
+                           (int64_t)N, (int64_t)0, 0x7fffffff, out, accumulate, strips);
+    }
+    ASR_CHECK_LAUNCH("colsum_kernel");
+    return ASR_OK;
+}
+
+extern "C" int64_t asr_colsum_ws_floats(int M, int N) { return (int64_t)cdiv(M > 0 ? M : 1, CS_ROWS) * N; }
+
+// ------------------------------------------------------------- transpose --
+__global__ __launch_bounds__(256) void transpose_kernel(const float *__restrict__ in,
+                                                        float *__restrict__ out, int R, int C) {
+    __shared__ float tile[32][33];
+    const float *src = in + (int64_t)blockIdx.z * R * C;
+    float *dst = out + (int64_t)blockIdx.z * R * C;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+    for (int i = ty; i < 32; i += 8) {
+        int r = r0 + i, c = c0 + tx;
+        tile[i][tx] = (r < R && c < C) ? src[(int64_t)r * C + c] : 0.f;
+    }
+    __syncthreads();
+    for (int i = ty; i < 32; i += 8) {
+        int c = c0 + i, r = r0 + tx;
+        if (r < R && c < C) dst[(int64_t)c * R + r] = tile[tx][i];
+    }
+}
+
+extern "C" int asr_transpose(const float *in, float *out, int R, int C, int nbatch, void *stream) {
+    ASR_CHECK_ARG(in && out && R > 0 && C > 0 && nbatch > 0, "transpose: bad argument");
+    hipLaunchKernelGGL(transpose_kernel, dim3(cdiv(C, 32), cdiv(R, 32), nbatch), dim3(256), 0,
+                       (hipStream_t)stream, in, out, R, C);
+    ASR_CHECK_LAUNCH("transpose_kernel");
+    return ASR_OK;
+}
+
+// ---------------------------------------------- embedding-gradient gather --
+// table[v][:] = sum over rows i with idx[i] == v of src[i][:]   (Models/decoder.py:57,
+// gradient of the L_ys lookup).  One block per table row scans the index list in
+// order, so the sum is deterministic and needs no atomics.
+__global__ __launch_bounds__(256) void scatter_rows_kernel(const float *__restrict__ src,
+                                                           const int64_t *__restrict__ idx, int n_rows,
+                                                           int width, int64_t src_stride,
+                                                           float *__restrict__ table) {
+    __shared__ int hits[256];
+    __shared__ int nhit;
+    const int v = blockIdx.x;
+    float *dst = table + (int64_t)v * width;
+    for (int c0 = 0; c0 < width; c0 += 256 * 8) {
+        float acc[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc[u] = 0.f;
+        for (int base = 0; base < n_rows; base += 256) {
+            __syncthreads();
+            if (threadIdx.x == 0) nhit = 0;
+            __syncthreads();
+            const int i = base + threadIdx.x;
+            if (i < n_rows && idx[i] == v) hits[atomicAdd(&nhit, 1)] = i;
+            __syncthreads();
+            const int n = nhit;
+            // deterministic order: sort the (few) hits of this chunk by row index
+            if (threadIdx.x == 0 && n > 1) {
+                for (int a = 1; a < n; ++a) {
+                    int key = hits[a], p = a - 1;
+                    while (p >= 0 && hits[p] > key) { hits[p + 1] = hits[p]; --p; }
+                    hits[p + 1] = key;
+                }
+            }
+            __syncthreads();
+            for (int h = 0; h < n; ++h) {
+                const float *row = src + (int64_t)hits[h] * src_stride;
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    int c = c0 + u * 256 + threadIdx.x;
+                    if (c < width) acc[u] += row[c];
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            int c = c0 + u * 256 + threadIdx.x;
+            if (c < width) dst[c] = acc[u];
+        }
+    }
+}
+
+extern "C" int asr_scatter_rows(const float *src, const int64_t *idx, int n_rows, int width,
+                                int64_t src_stride, float *table, int n_table_rows, void *stream) {
+    ASR_CHECK_ARG(src && idx && table, "scatter_rows: null pointer");
+    ASR_CHECK_ARG(n_rows >= 0 && width > 0 && n_table_rows > 0, "scatter_rows: bad shape");
+    hipLaunchKernelGGL(scatter_rows_kernel, dim3(n_table_rows), dim3(256), 0, (hipStream_t)stream, src,
+                       idx, n_rows, width, src_stride, table);
+    ASR_CHECK_LAUNCH("scatter_rows_kernel");
+    return ASR_OK;
+}
+
+// ---------------------------------------------------------------- dropout --
+__device__ __forceinline__ uint32_t mix32(uint64_t x) {
+    x ^= x >> 33; x *= 0xff51afd7ed558ccdULL;
+    x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ULL;
+    x ^= x >> 33;
+    return (uint32_t)x;
+}
+
+__global__ __launch_bounds__(256) void dropout_fwd_kernel(const float *__restrict__ x, float *__restrict__ y,
+                                                          uint8_t *__restrict__ mask, int64_t n,
+                                                          uint32_t thresh, float scale, uint64_t seed) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const uint8_t keep = mix32(seed + (uint64_t)i * 0x9E3779B97F4A7C15ULL) >= thresh;
+        mask[i] = keep;
+        y[i] = keep ? x[i] * scale : 0.f;
+    }
+}
+__global__ __launch_bounds__(256) void dropout_bwd_kernel(const float *__restrict__ dy,
+                                                          const uint8_t *__restrict__ mask,
+                                                          float *__restrict__ dx, int64_t n, float scale) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
+        dx[i] = mask[i] ? dy[i] * scale : 0.f;
+}
+
+extern "C" int asr_dropout_fwd(const float *x, float *y, uint8_t *mask, int64_t n, float p, uint64_t seed,
+                               void *stream) {
+    ASR_CHECK_ARG(x && y && mask && n >= 0 && p >= 0.f && p < 1.f, "dropout_fwd: bad argument");
+    if (n == 0) return ASR_OK;
+    const uint32_t thresh = (uint32_t)((double)p * 4294967296.0);
+    const int blocks = (int)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256);
+    hipLaunchKernelGGL(dropout_fwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, y, mask, n,
+                       thresh, 1.0f / (1.0f - p), seed);
+    ASR_CHECK_LAUNCH("dropout_fwd_kernel");
+    return ASR_OK;
+}
+extern "C" int asr_dropout_bwd(const float *dy, const uint8_t *mask, float *dx, int64_t n, float p,
+                               void *stream) {
+    ASR_CHECK_ARG(dy && dx && mask && n >= 0 && p >= 0.f && p < 1.f, "dropout_bwd: bad argument");
+    if (n == 0) return ASR_OK;
+    const int blocks = (int)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256);
+    hipLaunchKernelGGL(dropout_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, dy, mask, dx, n,
+                       1.0f / (1.0f - p));
+    ASR_CHECK_LAUNCH("dropout_bwd_kernel");
+    return ASR_OK;
+}
+
+// ------------------------------------------------------------ elementwise --
+// out = dU * (1 - U^2): gradient through u = tanh(.) of Models/decoder.py:55
+__global__ __launch_bounds__(256) void mul_dtanh_kernel(const float *__restrict__ dU,
+                                                        const float *__restrict__ U,
+                                                        float *__restrict__ out, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const float u = U[i];
+        out[i] = dU[i] * (1.f - u * u);
+    }
+}
+extern "C" int asr_mul_dtanh(const float *dU, const float *U, float *out, int64_t n, void *stream) {
+    ASR_CHECK_ARG(dU && U && out && n >= 0, "mul_dtanh: bad argument");
+    if (n == 0) return ASR_OK;
+    const int blocks = (int)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256);
+    hipLaunchKernelGGL(mul_dtanh_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, dU, U, out, n);
+    ASR_CHECK_LAUNCH("mul_dtanh_kernel");
+    return ASR_OK;
+}
+
+// out[i] = a[i] + b[i] (bias fusion b_ih + b_hh for both directions etc.)
+__global__ __launch_bounds__(256) void scale_kernel(float *__restrict__ x, int64_t n, float s) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) x[i] *= s;
+}
+extern "C" int asr_scale(float *x, int64_t n, float s, void *stream) {
+    ASR_CHECK_ARG(x && n >= 0, "scale: bad argument");
+    if (n == 0) return ASR_OK;
+    const int blocks = (int)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256);
+    hipLaunchKernelGGL(scale_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, n, s);
+    ASR_CHECK_LAUNCH("scale_kernel");
+    return ASR_OK;
+}

@@ -1,0 +1,142 @@
+"""Thin torch-tensor wrappers over the C ABI (pointers + sizes only cross it).
+
+PyTorch is plumbing here: it owns device memory and the stream.  Every
+function enqueues HIP kernels of libasr_amd.so on the current stream and
+returns without synchronising.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import GemmDesc, check
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t):
+    return C.c_void_p(0 if t is None else t.data_ptr())
+
+
+def _req(t, dtype=torch.float32):
+    if not t.is_cuda:
+        raise RuntimeError("asr_amd: tensors must live on the GPU (no CPU path exists)")
+    if t.dtype != dtype:
+        raise RuntimeError(f"asr_amd: expected {dtype}, got {t.dtype}")
+    return t
+
+
+def sgemm(A, B, Cm, M, N, K, *, a_mode=0, b_mode=0, a_stride=None, b_stride=None, c_stride=None,
+          a_two=None, b_two=None, c_two=None, bias1=None, bias2=None, alpha=1.0, accumulate=False,
+          act=0, splitk=1, nbatch=1, batch_a=0, batch_b=0, batch_c=0, a_off=0, b_off=0, c_off=0):
+    """C[m,n] (+)= alpha * sum_k A(m,k) B(n,k) (+ biases); see include/asr_amd.h.
+
+    *_stride: single row stride (elements); *_two = (d, s0, s1): two-level row
+    offset (i // d) * s1 + (i % d) * s0.  *_off: element offsets into the tensors.
+    """
+    lib = _lib.load()
+    d = GemmDesc()
+    es = 4
+    d.A = A.data_ptr() + a_off * es
+    d.B = B.data_ptr() + b_off * es
+    d.C = Cm.data_ptr() + c_off * es
+    d.M, d.N, d.K = M, N, K
+    d.a_mode, d.b_mode = a_mode, b_mode
+    for name, two, stride in (("a", a_two, a_stride), ("b", b_two, b_stride), ("c", c_two, c_stride)):
+        if two is not None:
+            dd, s0, s1 = two
+        else:
+            dd, s0, s1 = 0, stride, 0
+        setattr(d, name + "_d", dd)
+        setattr(d, name + "_s0", s0)
+        setattr(d, name + "_s1", s1)
+    d.bias1 = 0 if bias1 is None else bias1.data_ptr()
+    d.bias2 = 0 if bias2 is None else bias2.data_ptr()
+    d.alpha = alpha
+    d.accumulate = int(accumulate)
+    d.act = act
+    d.splitk = splitk
+    d.nbatch = nbatch
+    d.batch_a, d.batch_b, d.batch_c = batch_a, batch_b, batch_c
+    check(lib.asr_sgemm(C.byref(d), _stream()))
+
+
+def pick_splitk(M, N, K, nbatch=1):
+    """Split K until the launch has roughly one wave of 64x64..128x128 tiles per CU."""
+    tiles = ((M + 127) // 128) * ((N + 127) // 128) * nbatch
+    if tiles >= 192 or K < 512:
+        return 1
+    tiles64 = ((M + 63) // 64) * ((N + 63) // 64) * nbatch
+    want = max(1, 512 // max(tiles64, 1))
+    return int(max(1, min(want, K // 128, 64)))
+
+
+def linear_nt(x2d, W, out2d, bias1=None, bias2=None, act=0, accumulate=False):
+    """out = x2d @ W^T (+bias): x2d (M,K) and W (N,K) row-major contiguous."""
+    M, K = x2d.shape
+    N = W.shape[0]
+    sgemm(x2d, W, out2d, M, N, K, a_stride=x2d.stride(0), b_stride=W.stride(0), c_stride=out2d.stride(0),
+          bias1=bias1, bias2=bias2, act=act, accumulate=accumulate)
+
+
+def matmul_nn(x2d, W, out2d, accumulate=False):
+    """out = x2d @ W: x2d (M,K), W (K,N) row-major."""
+    M, K = x2d.shape
+    N = W.shape[1]
+    sgemm(x2d, W, out2d, M, N, K, a_stride=x2d.stride(0), b_mode=1, b_stride=W.stride(0),
+          c_stride=out2d.stride(0), accumulate=accumulate)
+
+
+def matmul_tn(a2d, b2d, out2d):
+    """out (M,N) = a2d^T @ b2d with a2d (K,M), b2d (K,N) row-major (weight gradients).
+
+    K is split over workgroups when M x N alone cannot fill the chip; out is
+    zeroed first because the split-K partials are summed with float atomics.
+    """
+    K, M = a2d.shape
+    N = b2d.shape[1]
+    sk = pick_splitk(M, N, K)
+    if sk > 1:
+        out2d.zero_()
+    sgemm(a2d, b2d, out2d, M, N, K, a_mode=1, a_stride=a2d.stride(0), b_mode=1, b_stride=b2d.stride(0),
+          c_stride=out2d.stride(0), splitk=sk)
+
+
+def colsum(a2d, out, accumulate=False):
+    lib = _lib.load()
+    M, N = a2d.shape
+    nws = int(lib.asr_colsum_ws_floats(M, N))
+    part = torch.empty(nws, device=a2d.device, dtype=torch.float32)
+    check(lib.asr_colsum(_p(a2d), M, N, a2d.stride(0), 0, 0, _p(out), int(accumulate), _p(part), _stream()))
+
+
+def transpose(x2d):
+    """Contiguous (R,C) -> new contiguous (C,R); leading dims are batched."""
+    lib = _lib.load()
+    *lead, R, Cc = x2d.shape
+    nb = 1
+    for v in lead:
+        nb *= v
+    out = torch.empty(*lead, Cc, R, device=x2d.device, dtype=torch.float32)
+    check(lib.asr_transpose(_p(x2d), _p(out), R, Cc, nb, _stream()))
+    return out
+
+
+def scatter_rows(src2d, idx, table):
+    lib = _lib.load()
+    n, w = src2d.shape
+    check(lib.asr_scatter_rows(_p(src2d), _p(idx), n, w, src2d.stride(0), _p(table), table.shape[0], _stream()))
+
+
+def mul_dtanh(dU, U):
+    lib = _lib.load()
+    out = torch.empty_like(U)
+    check(lib.asr_mul_dtanh(_p(dU), _p(U), _p(out), U.numel(), _stream()))
+    return out
+
+
+def scale_(x, s):
+    check(_lib.load().asr_scale(_p(x), x.numel(), float(s), _stream()))
+    return x

@@ -1,0 +1,95 @@
+"""Data-parallel gradient exchange: bucketed all-reduce on RCCL, overlapped with backward.
+
+The reference's only collective is the gradient all-reduce hidden inside
+``DistributedDataParallel`` (train.py:141, NCCL, mean over ranks).  Stock DDP
+still works on the ``asr_amd`` module (the drop-in path); this reducer is the
+MI355X-first version: buckets follow the order in which the HIP backward
+finishes gradients -- decoder+attention first (final when the decoder BPTT
+ends, overlapping the whole encoder backward), then encoder layers top-down --
+and each bucket is one flat fp32 buffer, so every all-reduce is a single large
+RCCL call (xGMI is point-to-point: few large messages beat many small ones).
+The 1/world_size of DDP's mean is applied with asr_scale when the bucket lands.
+"""
+import torch
+import torch.distributed as dist
+
+from . import ops
+
+
+class BucketedGradReducer:
+    def __init__(self, model, process_group=None):
+        self.model = model
+        self.group = process_group
+        self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        enc, dec = model.encoder, model.decoder
+        self.buckets = []                       # list of lists of parameters, in backward-completion order
+        self.buckets.append(list(dec.parameters()))
+        n_layers = enc.num_layers
+        for layer in range(n_layers - 1, -1, -1):
+            names = [f"{k}_l{layer}{sfx}" for sfx in ("", "_reverse")
+                     for k in ("weight_ih", "weight_hh", "bias_ih", "bias_hh")]
+            self.buckets.append([getattr(enc.bi_lstm, n) for n in names])
+        self.flat = [None] * len(self.buckets)
+        self.work = [None] * len(self.buckets)
+        self._pending = set()
+        self._hooks = []
+        self._counts = [0] * len(self.buckets)
+        self._where = {}
+        for bi, ps in enumerate(self.buckets):
+            for p in ps:
+                self._where[p] = bi
+                if self.world > 1:
+                    self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
+
+    def broadcast_parameters(self, src=0):
+        """One-time parameter broadcast from rank 0 (what DDP does at wrap time)."""
+        if self.world == 1:
+            return
+        for p in self.model.parameters():
+            dist.broadcast(p.data, src=src, group=self.group)
+
+    def _on_grad(self, p):
+        bi = self._where[p]
+        self._counts[bi] += 1
+        if self._counts[bi] == len(self.buckets[bi]):
+            self._launch(bi)
+
+    def _launch(self, bi):
+        ps = self.buckets[bi]
+        n = sum(p.numel() for p in ps)
+        if self.flat[bi] is None or self.flat[bi].numel() != n:
+            self.flat[bi] = torch.empty(n, device=ps[0].device, dtype=torch.float32)
+        flat = self.flat[bi]
+        o = 0
+        for p in ps:
+            flat[o:o + p.numel()].copy_(p.grad.reshape(-1))
+            o += p.numel()
+        # async_op: RCCL runs on the process group's own stream, ordered after the
+        # kernels enqueued so far; the backward keeps issuing work on this stream
+        self.work[bi] = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+
+    def finish(self):
+        """Wait for every bucket, apply DDP's mean and scatter back into ``.grad``."""
+        if self.world == 1:
+            return
+        for bi, ps in enumerate(self.buckets):
+            if self.work[bi] is None:
+                if all(p.grad is not None for p in ps):
+                    self._launch(bi)     # hooks did not fire (e.g. grads set manually)
+                else:
+                    continue
+            self.work[bi].wait()
+            flat = self.flat[bi]
+            if flat.is_cuda:
+                ops.scale_(flat, 1.0 / self.world)
+            else:
+                flat.mul_(1.0 / self.world)     # gloo/CPU rehearsal of the same bucket logic
+            o = 0
+            for p in ps:
+                p.grad.copy_(flat[o:o + p.numel()].view_as(p.grad))
+                o += p.numel()
+            self.work[bi] = None
+            self._counts[bi] = 0
+
+    def bytes_per_step(self):
+        return 4 * sum(p.numel() for ps in self.buckets for p in ps)

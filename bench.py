@@ -1,0 +1,234 @@
+"""Benchmark of the AttModel training hot path on MI355X (BASELINE.json metric).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+
+metric  : train frames/sec (fwd+bwd) -- sum of mel (10 ms fbank) frames in the
+          batch / wall seconds of {forward + label-smoothed CE + backward
+          (+ gradient all-reduce complete, N > 1)}; whole-job aggregate over ranks.
+workload: BASELINE config 2: B=32 per GPU, 80-dim fbank,
+          T_mel = linspace(1500, 900, 32), frame stacking 3 (T=500, D=240),
+          5-layer BLSTM H=320, V=1000, L=100, fp32, synthetic N(0,1) features,
+          random-init weights (seed 1234), inputs resident in HBM.
+A "step" is one such pass over one batch.  For N > 1 it is launched by
+torch.distributed.run, one rank per GPU, each rank its own batch (weak scaling),
+gradients all-reduced in buckets on RCCL (asr_amd/parallel.py).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
+MFMA_F32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: fp32-input MFMA = vector peak
+
+
+def make_hp(**kw):
+    """hparams_template defaults for the attributes the hot path reads."""
+    import types
+    d = dict(lmfb_dim=80, frame_stacking=3, num_hidden_nodes=320, num_encoder_layer=5, encoder_dropout=0.2,
+             encoder_type=None, decoder_type='Attention', num_classes=1000, eos_id=1, T_norm=True, B_norm=False,
+             beam_width=1, max_decoder_seq_len=200, clip=5.0, lr=1e-3, batch_size=32)
+    d.update(kw)
+    d.setdefault('num_hidden_nodes_encoder', d['num_hidden_nodes'])
+    d.setdefault('num_hidden_nodes_decoder', d['num_hidden_nodes'])
+    return types.SimpleNamespace(**d)
+
+
+def make_batch(hp, dev, seed=1234, B=32, t_hi=1500, t_lo=900, L=100, l_lo=50):
+    """Synthetic batch of BASELINE config 2, already frame-stacked (a view in the
+    reference, utils/utils.py:47-65).  Returns x (B,T,D) on dev, lengths (B,) CPU
+    int64 (stacked), targets (B,L) dev, text_lengths (B,) dev."""
+    g = torch.Generator().manual_seed(seed)
+    mel_len = torch.linspace(t_hi, t_lo, B).long()
+    text_len = torch.linspace(L, l_lo, B).long()
+    T_mel = int(mel_len.max())
+    st = hp.frame_stacking
+    mel = torch.randn(B, T_mel, hp.lmfb_dim, generator=g)
+    tgt = torch.randint(0, hp.num_classes, (B, L), generator=g)
+    for b in range(B):
+        mel[b, mel_len[b]:] = 0
+        tgt[b, text_len[b]:] = 0
+    n = T_mel // st
+    x = mel[:, : n * st].reshape(B, n, -1).contiguous()
+    lengths = mel_len // st
+    make_batch.mel_frames = int(mel_len.sum())
+    return x.to(dev), lengths, tgt.to(dev), text_len.to(dev)
+
+
+def cpu_baseline(hp, seconds_hint=25.0):
+    """The CPU restatement of the reference (oracle/ref_model.py, stock PyTorch
+    ops in the reference's op order) timed on this host: fwd + loss + bwd on a
+    bounded sample of the same workload -- every 4th utterance of the batch (B=8)."""
+    from oracle import ref_model as R
+    threads = min(os.cpu_count() or 1, int(os.environ.get("OMP_NUM_THREADS", "16")), 16)
+    torch.set_num_threads(threads)
+    torch.manual_seed(1234)
+    m = R.AttModel(hp).train()
+    cpu = torch.device("cpu")
+    x, lengths, tgt, tl = make_batch(hp, cpu)
+    sel = torch.arange(0, x.shape[0], 4)
+    x, lengths, tgt, tl = x[sel].contiguous(), lengths[sel], tgt[sel].contiguous(), tl[sel]
+    frames = int((lengths * hp.frame_stacking).sum())   # mel frames (multiples of 3 here)
+    t0 = time.time()
+    y = m(x, lengths, tgt)
+    loss = R.label_smoothing_loss(y, tgt, tl, hp.T_norm, hp.B_norm)
+    loss.backward()
+    dt = time.time() - t0
+    return {"value": frames / dt, "unit": "frames/s", "cores": threads, "kind": "port",
+            "sample": f"1 step fwd+loss+bwd of every 4th utterance of the config-2 batch (B=8, {frames} mel "
+                      f"frames, L=100) in {dt:.1f} s with torch CPU ops on {threads} threads"}
+
+
+def time_kernel_events(fn, iters):
+    """Average duration of one enqueue of fn() from HIP events on the current stream."""
+    e0 = torch.cuda.Event(enable_timing=True)
+    e1 = torch.cuda.Event(enable_timing=True)
+    fn()
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) * 1e-3 / iters
+
+
+def roofline_probe(hp, dev):
+    """Times the dominant kernels of the step in isolation with HIP events (same
+    shapes as the timed step) and prices them against the gfx950 peaks."""
+    from asr_amd import ops
+    H = hp.num_hidden_nodes_encoder
+    B, T = 32, 500
+    out = {}
+    # (1) input-projection GEMM of an upper encoder layer: (T*B x 2H) @ (2H x 4H), fp32 MFMA
+    M, N, K = T * B, 4 * H, 2 * H
+    g = torch.Generator(device="cpu").manual_seed(1)
+    A = torch.randn(M, K, generator=g).to(dev)
+    W = torch.randn(N, K, generator=g).to(dev)
+    Cm = torch.empty(M, N, device=dev)
+    dt = time_kernel_events(lambda: ops.sgemm(A, W, Cm, M, N, K, a_stride=K, b_stride=K, c_stride=N), 20)
+    flops = 2.0 * M * N * K
+    out["sgemm_proj"] = {"bound": "mfma", "achieved": flops / dt / 1e12, "peak": MFMA_F32_PEAK_TFLOPS,
+                         "unit": "TFLOP/s", "frac": flops / dt / 1e12 / MFMA_F32_PEAK_TFLOPS, "traffic": None,
+                         "kernel": "sgemm_kernel<128,128>", "shape": [M, N, K], "avg_us": dt * 1e6}
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dropout", type=float, default=0.2, help="encoder dropout (template default 0.2)")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from asr_amd.Loss.label_smoothing import label_smoothing_loss
+    from asr_amd.Models.AttModel import AttModel
+    from asr_amd.parallel import BucketedGradReducer
+
+    hp = make_hp(encoder_dropout=args.dropout)
+    torch.manual_seed(1234)                      # identical weights on every rank
+    model = AttModel(hp).to(dev).train()
+    reducer = BucketedGradReducer(model)
+    reducer.broadcast_parameters()
+    x, lengths, tgt, tl = make_batch(hp, dev, seed=1234 + rank)
+    frames = make_batch.mel_frames
+    opt = torch.optim.Adam(model.parameters(), lr=hp.lr, weight_decay=1e-5)
+
+    def step():
+        for p in model.parameters():
+            p.grad = None
+        y = model(x, lengths, tgt)
+        loss = label_smoothing_loss(y, tgt, tl, hp.T_norm, hp.B_norm)
+        loss.backward()
+        reducer.finish()
+        return loss
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        import torch.distributed as dist
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt)
+        ft = torch.tensor([frames], device=dev, dtype=torch.float64)
+        dist.all_reduce(ft, op=dist.ReduceOp.SUM)
+        total_frames = float(ft)
+    else:
+        total_frames = float(frames)
+    ms = dt / args.steps * 1e3
+
+    # full optimiser step (clip + Adam, train.py:60-63), reported beside the metric
+    full_ms = None
+    if rank == 0 or world > 1:
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(max(2, args.steps // 2)):
+            step()
+            torch.nn.utils.clip_grad_norm_(model.parameters(), hp.clip)
+            opt.step()
+        barrier()
+        full_ms = (time.perf_counter() - t0) / max(2, args.steps // 2) * 1e3
+
+    if rank == 0:
+        res = {
+            "metric": "train frames/sec (fwd+bwd), AttModel 1k-BPE LibriSpeech shape",
+            "value": total_frames / (ms * 1e-3),
+            "unit": "frames/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": "BASELINE config 2: B=32/GPU, T_mel linspace(1500,900), stack 3 -> T=500, "
+                                   "D=240, 5xBLSTM H=320, V=1000, L=100",
+                       "global_batch": 32 * world, "parallelism": f"dp{world}",
+                       "encoder_dropout": args.dropout, "loss": float(loss)},
+            "stacked_frames_per_s": total_frames / 3.0 / (ms * 1e-3),
+            "full_step_ms_with_clip_adam": full_ms,
+        }
+        probes = roofline_probe(hp, dev) if world == 1 else {}
+        if probes:
+            res["roofline"] = {k: v for k, v in probes["sgemm_proj"].items()}
+            res["roofline_all"] = probes
+        if world == 1 and not args.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(make_hp(encoder_dropout=0.0))
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -79,7 +79,8 @@ typedef struct {
     int64_t c_s0, c_s1; int c_d;
     const float *bias1, *bias2;
     float alpha;
-    int accumulate;
+    int accumulate;     /* C += result (read-modify-write) */
+    int act;            /* 0 none, 1 tanh applied to the stored value (splitk must be 1) */
     int splitk;
     int nbatch;
     int64_t batch_a, batch_b, batch_c;
@@ -88,14 +89,22 @@ typedef struct {
 int asr_sgemm(const asr_gemm_desc *d, void *stream);
 
 /* small helpers used by the backward passes (bias gradients, layouts) */
-/* out[n] (+)= sum_m A[rowoff(m) + n]; accumulate != 0 keeps the old value */
+/* out[n] (+)= sum_m A[rowoff(m) + n]; accumulate != 0 keeps the old value.
+ * part: asr_colsum_ws_floats(M,N) floats of scratch (may be NULL for small M);
+ * two-stage and atomic-free, so the sum is deterministic. */
 int asr_colsum(const float *A, int M, int N, int64_t s0, int64_t s1, int d,
-               float *out, int accumulate, void *stream);
+               float *out, int accumulate, float *part, void *stream);
+int64_t asr_colsum_ws_floats(int M, int N);
 /* out[c*R + r] = in[r*C + c], nbatch matrices back to back */
 int asr_transpose(const float *in, float *out, int R, int C, int nbatch, void *stream);
-/* table[idx[i]][:] += src[i][:]  (embedding gradient, Models/decoder.py:57 L_ys) */
-int asr_scatter_add_rows(const float *src, const int64_t *idx, int n_rows, int width,
-                         int64_t src_stride, float *table, void *stream);
+/* table[v][:] = sum_{i: idx[i]==v} src[i][:]  for every v < n_table_rows (embedding
+ * gradient of L_ys, Models/decoder.py:57); deterministic, overwrites table. */
+int asr_scatter_rows(const float *src, const int64_t *idx, int n_rows, int width,
+                     int64_t src_stride, float *table, int n_table_rows, void *stream);
+/* out = dU * (1 - U*U): gradient through u = tanh(.) of Models/decoder.py:55 */
+int asr_mul_dtanh(const float *dU, const float *U, float *out, int64_t n, void *stream);
+/* x *= s (1/world_size after the gradient all-reduce: DDP averages, train.py:141) */
+int asr_scale(float *x, int64_t n, float s, void *stream);
 
 /* ----------------------------------------------------------------- BLSTM --
  * One bidirectional LSTM layer over a ragged batch WITHOUT packing: the
@@ -143,6 +152,10 @@ int asr_dropout_bwd(const float *dy, const uint8_t *mask, float *dx, int64_t n, 
  *
  * Dimensions: B batch, T frames, E encoder width (2*H_enc), Hd decoder width,
  * A = 2*Hd attention width, L label steps.  NC=10 conv channels, KW=100 taps.
+ *
+ * Hoisted by the caller (asr_sgemm): PH = L_he(hbatch) before the call;
+ * U = tanh(L_gy g + b_gy + L_sy S[0..L-1]) and youtput = L_yy U after it
+ * (neither is on the recurrent chain).
  */
 typedef struct {
     int B, T, E, Hd, L, V;
@@ -156,9 +169,6 @@ typedef struct {
     const float *w_ee;        /* (A)      att.L_ee.weight */
     const float *W_fe;        /* (A,10)   att.L_fe.weight */
     const float *conv_w;      /* (10,100) att.F_conv1d.weight */
-    const float *W_sy;        /* (Hd,Hd)  */
-    const float *W_gy;        /* (Hd,E)   */
-    const float *b_gy;        /* (Hd)     */
     const float *Emb;         /* (V,4Hd)  L_ys.weight */
     const float *W_ss;        /* (4Hd,Hd) */
     const float *W_gs;        /* (4Hd,E)  */
@@ -166,17 +176,26 @@ typedef struct {
     /* saved activations (outputs of fwd, inputs of bwd) */
     float *S;                 /* (L+1,B,Hd) decoder state, S[0]=0 */
     float *C;                 /* (L+1,B,Hd) cell state,   C[0]=0 */
-    float *alpha;             /* (L,B,T)   alignments */
+    float *alpha;             /* (L,B,T)   alignments (0 at t >= lengths[b]) */
     float *sproj;             /* (L,B,A)   L_se(s) per step */
     float *g;                 /* (L,B,E)   contexts */
-    float *U;                 /* (B,L,Hd)  tanh(L_gy g + L_sy s): input of the hoisted L_yy GEMM */
     float *gates;             /* (L,B,4Hd) activated cell gates */
+    float *Fc;                /* (L,B,T,10) conv features of alpha_{s-1} */
     /* workspace */
     float *ws;                /* asr_attdec_ws_floats() floats */
 } asr_attdec_fwd_args;
 
 int64_t asr_attdec_ws_floats(int B, int T, int E, int Hd, int L);
 int asr_attdec_fwd(const asr_attdec_fwd_args *a, void *stream);
+
+/* Greedy search, batch 1: the beam_width == 1 path of Models/decoder.py:63-130.
+ * Runs a->L (= hp.max_decoder_seq_len) steps with the argmax of step s fed back
+ * as the label of step s; tokens (1,L) int64 receives the argmax sequence and
+ * must be the buffer a->targets points at.  The caller cuts at hp.eos_id
+ * (the reference returns [] when eos never appears). */
+int asr_attdec_greedy(const asr_attdec_fwd_args *a, const float *W_sy, const float *W_gy,
+                      const float *b_gy, const float *W_yy, const float *b_yy, int64_t *tokens,
+                      void *stream);
 
 typedef struct {
     asr_attdec_fwd_args f;    /* same tensors as the forward call */
@@ -187,19 +206,18 @@ typedef struct {
     const float *W_gsT;       /* (E,4Hd)  */
     const float *W_gyT;       /* (E,Hd)   */
     /* upstream */
-    const float *dU;          /* (B,L,Hd) = dY @ W_yy (asr_sgemm) */
+    const float *dyp;         /* (L,B,Hd) d loss / d (L_gy g + L_sy s) = dU * (1 - U^2) */
     /* per-step gradients saved for the hoisted weight-gradient GEMMs */
     float *drec;              /* (L,B,4Hd) d loss / d rec_input */
-    float *dyp;               /* (L,B,Hd)  d loss / d (L_gy g + L_sy s) */
-    float *dsp;               /* (L,B,A)   d loss / d L_se(s) */
+    float *dsp;               /* (L,B,A)   d loss / d L_se(s)  (dsp[0] = 0: S[0] = 0) */
     float *dg;                /* (L,B,E)   d loss / d context */
-    float *de;                /* (L,B,T)   d loss / d energy */
-    float *dF;                /* (L,B,T,10) d loss / d conv features */
+    float *de;                /* (L,B,T)   d loss / d energy  (valid at t < lengths[b]) */
+    float *dF;                /* (L,B,T,10) d loss / d conv features (valid at t < lengths[b]) */
     /* outputs */
     float *dPH;               /* (B,T,A)  */
-    float *dw_ee;             /* (A)      accumulated (caller zeroes) */
-    float *dW_fe;             /* (A,10)   accumulated (caller zeroes) */
-    float *dconv_w;           /* (10,100) accumulated (caller zeroes) */
+    float *dw_ee;             /* (A)      */
+    float *dW_fe;             /* (A,10)   */
+    float *dconv_w;           /* (10,100) */
     float *ws;                /* asr_attdec_bwd_ws_floats() floats */
 } asr_attdec_bwd_args;
 

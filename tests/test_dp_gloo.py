@@ -1,0 +1,59 @@
+"""CPU, world_size 2 over gloo: the bucketed gradient reducer averages gradients
+like DDP (train.py:141) and keeps the backward-completion bucket order."""
+import os
+import socket
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from asr_amd.Models.AttModel import AttModel
+    from asr_amd.parallel import BucketedGradReducer
+    from oracle import ref_model as R
+    hp = R.make_hp(num_hidden_nodes=8, num_encoder_layer=2, lmfb_dim=4, num_classes=7, frame_stacking=1)
+    torch.manual_seed(100 + rank)                  # different weights per rank on purpose
+    m = AttModel(hp)
+    red = BucketedGradReducer(m)
+    red.broadcast_parameters()
+    w0 = torch.cat([p.detach().reshape(-1) for p in m.parameters()])
+    g = torch.Generator().manual_seed(rank)
+    for p in m.parameters():
+        p.grad = torch.randn(p.shape, generator=g)
+    mine = torch.cat([p.grad.reshape(-1) for p in m.parameters()]).clone()
+    red.finish()
+    avg = torch.cat([p.grad.reshape(-1) for p in m.parameters()])
+    gathered = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(gathered, mine)
+    want = sum(gathered) / world
+    ws = [torch.zeros_like(w0) for _ in range(world)]
+    dist.all_gather(ws, w0)
+    ok = bool(torch.allclose(avg, want, atol=1e-6)) and all(torch.equal(ws[0], w) for w in ws)
+    # bucket order: decoder first, then encoder layers top-down
+    names = {p: n for n, p in m.named_parameters()}
+    order = [names[ps[0]] for ps in red.buckets]
+    ok = ok and order[0].startswith("decoder.") and order[1].endswith("_l1") and order[2].endswith("_l0")
+    ok = ok and red.bytes_per_step() == 4 * sum(p.numel() for p in m.parameters())
+    out[rank] = ok
+    dist.destroy_process_group()
+
+
+def test_reducer_world2_gloo():
+    world = 2
+    port = _free_port()
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker, args=(world, port, out), nprocs=world, join=True)
+    assert all(out.get(r) for r in range(world)), dict(out)

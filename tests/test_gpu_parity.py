@@ -1,0 +1,313 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the reference's golden
+vectors and against the CPU oracle on seeded inputs.
+
+Tolerances are the north star's fp32 bar: loss rel-err <= 1e-4, gradients
+<= 1e-3 (scale-relative max error, tests/_util.rel_err); youtput <= 1e-4.
+Greedy decoding must be token-identical.
+"""
+import numpy as np
+import pytest
+import torch
+
+from tests._util import CASES, load_case, params_of, rel_err, greedy_raw_from_table
+
+pytestmark = pytest.mark.gpu
+
+LOSS_TOL, OUT_TOL, GRAD_TOL = 1e-4, 1e-4, 1e-3
+
+
+def _dev():
+    assert torch.cuda.is_available(), "GPU tests need a GPU: refusing to pass on a fallback"
+    return torch.device("cuda:0")
+
+
+def _build(hp, state):
+    from asr_amd.Models.AttModel import AttModel
+    m = AttModel(hp)
+    m.load_state_dict(state)
+    return m.to(_dev()).train()
+
+
+# ------------------------------------------------------------------ sgemm --
+@pytest.mark.parametrize("M,N,K", [(1, 1, 1), (5, 7, 3), (64, 64, 16), (130, 70, 33), (257, 129, 100),
+                                   (300, 260, 64), (1000, 384, 40)])
+@pytest.mark.parametrize("a_mode,b_mode", [(0, 0), (0, 1), (1, 0), (1, 1)])
+def test_sgemm_modes(M, N, K, a_mode, b_mode):
+    from asr_amd import ops
+    dev = _dev()
+    g = torch.Generator().manual_seed(M * 7 + N * 3 + K + a_mode * 2 + b_mode)
+    A = torch.randn((M, K) if a_mode == 0 else (K, M), generator=g)
+    Bm = torch.randn((N, K) if b_mode == 0 else (K, N), generator=g)
+    bias = torch.randn(N, generator=g)
+    want = (A if a_mode == 0 else A.t()).double() @ (Bm if b_mode == 0 else Bm.t()).double().t() + bias.double()
+    Ad, Bd, bd = A.to(dev), Bm.to(dev), bias.to(dev)
+    out = torch.full((M, N), 7.0, device=dev)
+    ops.sgemm(Ad, Bd, out, M, N, K, a_mode=a_mode, b_mode=b_mode, a_stride=A.shape[1], b_stride=Bm.shape[1],
+              c_stride=N, bias1=bd)
+    assert rel_err(out.cpu(), want) < 2e-6
+    # accumulate + split-K (atomic) variants
+    out2 = torch.ones(M, N, device=dev)
+    ops.sgemm(Ad, Bd, out2, M, N, K, a_mode=a_mode, b_mode=b_mode, a_stride=A.shape[1], b_stride=Bm.shape[1],
+              c_stride=N, bias1=bd, accumulate=True)
+    assert rel_err(out2.cpu(), want + 1.0) < 2e-6
+    out3 = torch.zeros(M, N, device=dev)
+    ops.sgemm(Ad, Bd, out3, M, N, K, a_mode=a_mode, b_mode=b_mode, a_stride=A.shape[1], b_stride=Bm.shape[1],
+              c_stride=N, bias1=bd, splitk=3)
+    assert rel_err(out3.cpu(), want) < 2e-6
+
+
+def test_sgemm_two_level_and_batched():
+    from asr_amd import ops
+    dev = _dev()
+    g = torch.Generator().manual_seed(5)
+    B, T, D, N = 3, 11, 8, 20
+    x = torch.randn(B, T, D, generator=g)
+    W = torch.randn(N, D, generator=g)
+    out = torch.empty(T, B, N, device=dev)
+    ops.sgemm(x.to(dev), W.to(dev), out, T * B, N, D, a_two=(B, T * D, D), b_stride=D, c_stride=N)
+    want = torch.einsum("btd,nd->tbn", x.double(), W.double())
+    assert rel_err(out.cpu(), want) < 2e-6
+    # batched TN with accumulate: dh[b] += alpha[:, b]^T dg[:, b]
+    L, E = 6, 12
+    al = torch.randn(L, B, T, generator=g)
+    dg = torch.randn(L, B, E, generator=g)
+    dh0 = torch.randn(B, T, E, generator=g)
+    dh = dh0.clone().to(dev)
+    ops.sgemm(al.to(dev), dg.to(dev), dh, T, E, L, a_mode=1, a_stride=B * T, b_mode=1, b_stride=B * E,
+              c_stride=E, accumulate=True, nbatch=B, batch_a=T, batch_b=E, batch_c=T * E)
+    want = dh0.double() + torch.einsum("lbt,lbe->bte", al.double(), dg.double())
+    assert rel_err(dh.cpu(), want) < 2e-6
+
+
+def test_helpers():
+    from asr_amd import ops
+    dev = _dev()
+    g = torch.Generator().manual_seed(9)
+    a = torch.randn(1300, 70, generator=g)
+    out = torch.empty(70, device=dev)
+    ops.colsum(a.to(dev), out)
+    assert rel_err(out.cpu(), a.double().sum(0)) < 1e-6
+    x = torch.randn(2, 37, 50, generator=g)
+    assert torch.equal(ops.transpose(x.to(dev)).cpu(), x.transpose(1, 2).contiguous())
+    src = torch.randn(40, 24, generator=g)
+    idx = torch.randint(0, 9, (40,), generator=g)
+    table = torch.full((9, 24), 3.0, device=dev)
+    ops.scatter_rows(src.to(dev), idx.to(dev), table)
+    want = torch.zeros(9, 24, dtype=torch.float64).index_add_(0, idx, src.double())
+    assert rel_err(table.cpu(), want) < 1e-6
+
+
+# ------------------------------------------------------------------- loss --
+@pytest.mark.parametrize("B,L,V,T_norm,B_norm", [(3, 5, 11, True, False), (4, 7, 1000, True, True),
+                                                 (2, 9, 7000, False, False), (3, 4, 37, True, False),
+                                                 (2, 3, 5003, True, False)])
+def test_loss_kernel_vs_oracle(B, L, V, T_norm, B_norm):
+    from asr_amd.Loss.label_smoothing import label_smoothing_loss
+    from oracle import ref_model as R
+    dev = _dev()
+    g = torch.Generator().manual_seed(V + L)
+    z = (torch.randn(B, L, V, generator=g) * 3).requires_grad_(True)
+    tgt = torch.randint(0, V, (B, L), generator=g)
+    tl = torch.randint(1, L + 1, (B,), generator=g)
+    want = R.label_smoothing_loss(z.double(), tgt, tl, T_norm, B_norm)
+    gw, = torch.autograd.grad(want, z)
+    zd = z.detach().to(dev).requires_grad_(True)
+    got = label_smoothing_loss(zd, tgt.to(dev), tl.to(dev), T_norm, B_norm)
+    got.backward()
+    assert abs(float(got) - float(want)) / abs(float(want)) < 1e-5
+    assert rel_err(zd.grad.cpu(), gw) < 1e-5
+
+
+# ------------------------------------------------------ encoder / decoder --
+@pytest.mark.parametrize("B,T,D,H,N,lens", [(3, 17, 12, 8, 2, [17, 9, 4]), (5, 33, 6, 12, 1, [20, 33, 1, 33, 7]),
+                                            (18, 21, 10, 32, 3, None), (2, 40, 240, 320, 2, [40, 31])])
+def test_blstm_vs_oracle(B, T, D, H, N, lens):
+    from asr_amd.Models.encoder import Encoder
+    from oracle import ref_model as R
+    dev = _dev()
+    hp = R.make_hp(lmfb_dim=D, frame_stacking=1, num_hidden_nodes=H, num_encoder_layer=N, encoder_dropout=0.0)
+    torch.manual_seed(B * T + H)
+    ref = R.Encoder(hp).double()
+    lengths = torch.tensor(lens) if lens is not None else torch.randint(1, T + 1, (B,))
+    if lens is None:
+        lengths[0] = T
+    x = torch.randn(B, T, D)
+    for b in range(B):
+        x[b, lengths[b]:] = 0
+    xr = x.double().requires_grad_(True)
+    hr = ref(xr, lengths)
+    w = torch.randn(B, T, 2 * H).double()
+    (hr * w).sum().backward()
+    enc = Encoder(hp)
+    enc.load_state_dict({k: v.float() for k, v in ref.state_dict().items()})
+    enc = enc.to(dev).train()
+    xd = x.to(dev).requires_grad_(True)
+    hd = enc(xd, lengths)
+    (hd * w.float().to(dev)).sum().backward()
+    assert rel_err(hd.detach().cpu(), hr.detach()) < 2e-5
+    for b in range(B):
+        assert float(hd[b, lengths[b]:].abs().max() if lengths[b] < T else 0.0) == 0.0
+    assert rel_err(xd.grad.cpu(), xr.grad) < GRAD_TOL
+    for (k, p), (_, q) in zip(enc.named_parameters(), ref.named_parameters()):
+        assert rel_err(p.grad.cpu(), q.grad) < GRAD_TOL, k
+
+
+@pytest.mark.parametrize("B,T,He,Hd,V,L,lens", [(3, 17, 8, 8, 11, 5, [17, 9, 4]), (4, 70, 6, 10, 13, 6, [70, 64, 65, 1]),
+                                                (2, 130, 16, 320, 50, 4, [130, 77]), (17, 150, 12, 16, 9, 3, None)])
+def test_decoder_vs_oracle(B, T, He, Hd, V, L, lens):
+    from asr_amd.Models.decoder import Decoder
+    from oracle import ref_model as R
+    dev = _dev()
+    hp = R.make_hp(num_hidden_nodes_encoder=He, num_hidden_nodes_decoder=Hd, num_classes=V)
+    torch.manual_seed(T + Hd)
+    ref = R.Decoder(hp).double()
+    lengths = torch.tensor(lens) if lens is not None else torch.randint(1, T + 1, (B,))
+    h = torch.randn(B, T, 2 * He)
+    for b in range(B):
+        h[b, lengths[b]:] = 0
+    tgt = torch.randint(0, V, (B, L))
+    hr = h.double().requires_grad_(True)
+    yr = ref(hr, lengths, tgt)
+    w = torch.randn(B, L, V).double()
+    (yr * w).sum().backward()
+    dec = Decoder(hp)
+    dec.load_state_dict({k: v.float() for k, v in ref.state_dict().items()})
+    dec = dec.to(dev).train()
+    hd = h.to(dev).requires_grad_(True)
+    yd = dec(hd, lengths, tgt.to(dev))
+    (yd * w.float().to(dev)).sum().backward()
+    assert rel_err(yd.detach().cpu(), yr.detach()) < OUT_TOL
+    assert rel_err(hd.grad.cpu(), hr.grad) < GRAD_TOL
+    for (k, p), (_, q) in zip(dec.named_parameters(), ref.named_parameters()):
+        assert rel_err(p.grad.cpu(), q.grad) < GRAD_TOL, k
+
+
+# ------------------------------------------------- golden vectors (reference) --
+@pytest.mark.parametrize("name", CASES)
+def test_golden_forward_backward(name):
+    from asr_amd.Loss.label_smoothing import label_smoothing_loss
+    z, hp = load_case(name)
+    dev = _dev()
+    m = _build(hp, params_of(z))
+    x = torch.from_numpy(z["x"]).to(dev).requires_grad_(True)
+    lengths = torch.from_numpy(z["lengths"])
+    targets = torch.from_numpy(z["targets"]).to(dev)
+    tl = torch.from_numpy(z["text_lengths"]).to(dev)
+    y = m(x, lengths, targets)
+    loss = label_smoothing_loss(y, targets, tl, hp.T_norm, hp.B_norm)
+    loss.backward()
+    # anchor: the reference in float64 (its own float32 run differs from it by ~1e-6)
+    assert rel_err(y.detach().cpu(), z["f64.youtput"]) < OUT_TOL
+    assert abs(float(loss) - float(z["f64.loss"])) / abs(float(z["f64.loss"])) < LOSS_TOL
+    assert rel_err(x.grad.cpu(), z["f64.dx"]) < GRAD_TOL
+    for k, p in m.named_parameters():
+        assert rel_err(p.grad.cpu(), z[f"f64.grad.{k}"]) < GRAD_TOL, k
+    # and against the reference's float32 outputs themselves
+    assert rel_err(y.detach().cpu(), z["f32.youtput"]) < OUT_TOL
+    assert abs(float(loss) - float(z["f32.loss"])) / abs(float(z["f32.loss"])) < LOSS_TOL
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_golden_greedy_tokens(name):
+    z, hp = load_case(name)
+    dev = _dev()
+    m = _build(hp, params_of(z)).eval()
+    x = torch.from_numpy(z["x"]).to(dev)
+    lengths = torch.from_numpy(z["lengths"])
+    max_len = int(z["greedy.max_len"])
+    hp.max_decoder_seq_len = max_len
+    for utt in range(2):
+        if f"greedy.utt{utt}" not in z.files:
+            continue
+        table = z[f"greedy.utt{utt}"]
+        with torch.no_grad():
+            hb = m.encoder(x[utt:utt + 1], lengths[utt:utt + 1])
+            _, raw = m.decoder.decode_raw(hb, lengths[utt:utt + 1])
+        assert len(raw) == max_len
+        for eos in range(hp.num_classes):
+            want = [int(v) for v in table[eos] if v >= 0]
+            got = raw[:raw.index(eos) + 1] if eos in raw else []
+            assert got == want, (utt, eos)
+        # the public entry point with the reference's return convention
+        hp.eos_id = int(raw[1])
+        res = m.decode(x[utt:utt + 1], lengths[utt:utt + 1])
+        assert res == [int(v) for v in table[hp.eos_id] if v >= 0]
+
+
+# --------------------------------- production dims against the oracle, seeded --
+def test_librispeech_dims_small_batch_vs_oracle():
+    """hparams_template widths (H=320, 2 layers here, V=1000, stack 3 -> D=240) at a
+    batch the CPU oracle finishes in seconds; exercises the 16-byte vector paths."""
+    from asr_amd.Loss.label_smoothing import label_smoothing_loss
+    from oracle import ref_model as R
+    dev = _dev()
+    hp = R.make_hp(num_encoder_layer=2, encoder_dropout=0.0)
+    torch.manual_seed(1234)
+    ref = R.AttModel(hp)
+    B, T, L = 4, 48, 6
+    lengths = torch.tensor([48, 40, 33, 20])
+    tl = torch.tensor([6, 5, 3, 6])
+    x = torch.randn(B, T, 240)
+    tgt = torch.randint(0, 1000, (B, L))
+    for b in range(B):
+        x[b, lengths[b]:] = 0
+        tgt[b, tl[b]:] = 0
+    refd = R.AttModel(hp).double()
+    refd.load_state_dict({k: v.double() for k, v in ref.state_dict().items()})
+    xr = x.double().requires_grad_(True)
+    yr = refd(xr, lengths, tgt)
+    lr = R.label_smoothing_loss(yr, tgt, tl)
+    lr.backward()
+    m = _build(hp, ref.state_dict())
+    xd = x.to(dev).requires_grad_(True)
+    y = m(xd, lengths, tgt.to(dev))
+    loss = label_smoothing_loss(y, tgt.to(dev), tl.to(dev))
+    loss.backward()
+    assert rel_err(y.detach().cpu(), yr.detach()) < OUT_TOL
+    assert abs(float(loss) - float(lr)) / abs(float(lr)) < LOSS_TOL
+    assert rel_err(xd.grad.cpu(), xr.grad) < GRAD_TOL
+    for (k, p), (_, q) in zip(m.named_parameters(), refd.named_parameters()):
+        assert rel_err(p.grad.cpu(), q.grad) < GRAD_TOL, k
+
+
+def test_full_size_properties():
+    """BASELINE config 2 (B=32, T=500 stacked, L=100, V=1000, 5 layers): too slow for
+    the CPU oracle, so check size-independent properties: padded encoder rows are
+    exactly zero, every alignment row sums to 1 over the valid frames and is 0 past
+    them, the loss is finite, gradients are finite, and the gradient of the loss
+    along a random parameter direction matches a central finite difference."""
+    from asr_amd.Loss.label_smoothing import label_smoothing_loss
+    from asr_amd.Models.AttModel import AttModel
+    from oracle import ref_model as R
+    from bench import make_batch
+    dev = _dev()
+    hp = R.make_hp(encoder_dropout=0.0)
+    torch.manual_seed(1234)
+    m = AttModel(hp).to(dev).train()
+    x, lengths, tgt, tl = make_batch(hp, dev, seed=1234)
+    y = m(x, lengths, tgt)
+    loss = label_smoothing_loss(y, tgt, tl)
+    loss.backward()
+    assert torch.isfinite(loss)
+    for k, p in m.named_parameters():
+        assert torch.isfinite(p.grad).all(), k
+    with torch.no_grad():
+        hb = m.encoder(x, lengths)
+        for b in (0, 13, 31):
+            n = int(lengths[b])
+            if n < hb.shape[1]:
+                assert float(hb[b, n:].abs().max()) == 0.0
+        # directional derivative
+        torch.manual_seed(7)
+        dirs = {k: torch.randn_like(p) for k, p in m.named_parameters()}
+        analytic = sum(float((p.grad.double() * dirs[k].double()).sum()) for k, p in m.named_parameters())
+        eps = 2e-3
+        vals = []
+        for sgn in (+1, -1):
+            for k, p in m.named_parameters():
+                p.add_(dirs[k], alpha=sgn * eps)
+            vals.append(float(label_smoothing_loss(m(x, lengths, tgt), tgt, tl)))
+            for k, p in m.named_parameters():
+                p.add_(dirs[k], alpha=-sgn * eps)
+        fd = (vals[0] - vals[1]) / (2 * eps)
+    assert abs(fd - analytic) / max(abs(analytic), 1e-6) < 2e-2, (fd, analytic)
