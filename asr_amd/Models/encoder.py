@@ -50,6 +50,31 @@ def _stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+# Workspaces of the persistent recurrence kernels (flag words + h exchange), one
+# per (device, B, H), reused by every layer and step: launches on one stream are
+# serialised, and the library zeroes the flag words before each launch.  Word
+# ERR_WORD is sticky: a kernel sets it if an in-launch wait ever timed out.
+PERSISTENT = True          # False selects the one-launch-per-time-step kernels
+ERR_WORD = 1024
+_WS = {}
+
+
+def _persist_ws(lib, B, H, dev):
+    if not PERSISTENT:
+        return None
+    key = (dev.index, B, H)
+    ws = _WS.get(key)
+    if ws is None:
+        ws = torch.zeros(int(lib.asr_blstm_ws_floats(B, H)), device=dev, dtype=torch.float32)
+        _WS[key] = ws
+    return ws
+
+
+def persistent_error_flags():
+    """True if any persistent kernel reported a timed-out wait (device -> host copy)."""
+    return any(bool(ws.view(torch.int32)[ERR_WORD].item()) for ws in _WS.values())
+
+
 class _BLSTMLayerFunction(torch.autograd.Function):
     """One bidirectional layer.  Input is (B,T,D) batch-major for the first layer
     and (T,B,D) time-major otherwise; output is (B,T,2H) batch-major for the last
@@ -83,8 +108,9 @@ class _BLSTMLayerFunction(torch.autograd.Function):
         else:
             Hout = torch.empty(T, B, 2 * H, device=dev, dtype=torch.float32)
             ho_t, ho_b = B * 2 * H, 2 * H
+        ws = _persist_ws(lib, B, H, dev)
         check(lib.asr_blstm_fwd(W_hh.data_ptr(), G.data_ptr(), Cs.data_ptr(), Hout.data_ptr(), ho_t, ho_b,
-                                lengths_dev.data_ptr(), T, B, H, st))
+                                lengths_dev.data_ptr(), T, B, H, 0 if ws is None else ws.data_ptr(), st))
         ctx.save_for_backward(inp, G, Cs, Hout, lengths_dev, w_ih_f, w_hh_f, w_ih_r, w_hh_r)
         ctx.dims = (B, T, D, H, first, in_two, ho_t, ho_b)
         return Hout
@@ -100,8 +126,10 @@ class _BLSTMLayerFunction(torch.autograd.Function):
         f32 = dict(device=dev, dtype=torch.float32)
         dc_ws = torch.empty(2 * B * H, **f32)
         W_hhT = ops.transpose(torch.cat([w_hh_f, w_hh_r], 0).view(2, 4 * H, H))   # [2][H][4H]
+        ws = _persist_ws(lib, B, H, dev)
         check(lib.asr_blstm_bwd(W_hhT.data_ptr(), G.data_ptr(), Cs.data_ptr(), dHout.data_ptr(), ho_t, ho_b,
-                                lengths_dev.data_ptr(), dc_ws.data_ptr(), T, B, H, st))
+                                lengths_dev.data_ptr(), dc_ws.data_ptr(), T, B, H,
+                                0 if ws is None else ws.data_ptr(), st))
         dG = G.view(T * B, 8 * H)                  # now d loss / d pre-activation gates (0 at padding)
         db = torch.empty(8 * H, **f32)
         ops.colsum(dG, db)                         # b_ih and b_hh receive the same column sums

@@ -67,8 +67,10 @@ SYMBOLS = {
     "asr_scatter_rows": (C.c_int, [c_f, c_f, C.c_int, C.c_int, c_i64, c_f, C.c_int, c_f]),
     "asr_mul_dtanh": (C.c_int, [c_f, c_f, c_f, c_i64, c_f]),
     "asr_scale": (C.c_int, [c_f, c_i64, C.c_float, c_f]),
-    "asr_blstm_fwd": (C.c_int, [c_f, c_f, c_f, c_f, c_i64, c_i64, c_f, C.c_int, C.c_int, C.c_int, c_f]),
-    "asr_blstm_bwd": (C.c_int, [c_f, c_f, c_f, c_f, c_i64, c_i64, c_f, c_f, C.c_int, C.c_int, C.c_int, c_f]),
+    "asr_blstm_ws_floats": (c_i64, [C.c_int, C.c_int]),
+    "asr_blstm_fwd": (C.c_int, [c_f, c_f, c_f, c_f, c_i64, c_i64, c_f, C.c_int, C.c_int, C.c_int, c_f, c_f]),
+    "asr_blstm_bwd": (C.c_int, [c_f, c_f, c_f, c_f, c_i64, c_i64, c_f, c_f, C.c_int, C.c_int, C.c_int, c_f,
+                                c_f]),
     "asr_dropout_fwd": (C.c_int, [c_f, c_f, c_f, c_i64, C.c_float, C.c_uint64, c_f]),
     "asr_dropout_bwd": (C.c_int, [c_f, c_f, c_f, c_i64, C.c_float, c_f]),
     "asr_attdec_ws_floats": (c_i64, [C.c_int] * 5),

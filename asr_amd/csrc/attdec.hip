@@ -63,30 +63,42 @@ __device__ __forceinline__ void fill_uni(float *uni, const float *__restrict__ s
 }
 
 // Stage PH[b][t0 .. t0+63][ac .. ac+ACH) into tile[64][TSTR]; rows >= nrows and
-// columns >= A are zero.  Global reads are whole 512-byte row segments; the four
-// scalar LDS writes of a float4 are rotated so that each write instruction hits
-// distinct banks.
-__device__ __forceinline__ void stage_tile(float *tile, const float *__restrict__ PHb, int t0, int nrows,
-                                           int ac, int A, bool vec) {
+// columns >= A are zero.  Split in two so the global loads of chunk c+1 are in
+// flight while chunk c is being consumed: stage_load (whole 512-byte row
+// segments, 16 B per lane) -> registers, stage_write registers -> LDS with the
+// four scalar writes of a float4 rotated so each write instruction hits distinct
+// banks.
+#define STAGE_N ((TT * ACH / 4) / (EW * 64))
+__device__ __forceinline__ void stage_load(float4 (&regs)[STAGE_N], const float *__restrict__ PHb, int t0,
+                                           int nrows, int ac, int A, bool vec) {
     const int tid = threadIdx.x;
 #pragma unroll
-    for (int it = 0; it < (TT * ACH / 4) / (EW * 64); ++it) {
+    for (int it = 0; it < STAGE_N; ++it) {
         const int f = tid + it * (EW * 64);
         const int row = f / (ACH / 4), c4 = f % (ACH / 4);
         const int a = ac + c4 * 4;
-        float v[4] = {0.f, 0.f, 0.f, 0.f};
+        float4 v = zero4();
         if (row < nrows && a < A) {
             const float *src = PHb + (int64_t)(t0 + row) * A + a;
             if (vec && a + 3 < A) {
-                const float4 q = ld4(src);
-                v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
+                v = ld4(src);
             } else {
-                v[0] = src[0];
-                if (a + 1 < A) v[1] = src[1];
-                if (a + 2 < A) v[2] = src[2];
-                if (a + 3 < A) v[3] = src[3];
+                v.x = src[0];
+                if (a + 1 < A) v.y = src[1];
+                if (a + 2 < A) v.z = src[2];
+                if (a + 3 < A) v.w = src[3];
             }
         }
+        regs[it] = v;
+    }
+}
+__device__ __forceinline__ void stage_write(float *tile, const float4 (&regs)[STAGE_N]) {
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int it = 0; it < STAGE_N; ++it) {
+        const int f = tid + it * (EW * 64);
+        const int row = f / (ACH / 4), c4 = f % (ACH / 4);
+        const float v[4] = {regs[it].x, regs[it].y, regs[it].z, regs[it].w};
         float *dst = tile + row * TSTR + c4 * 4;
         const int rot = (c4 >> 3) & 3;
 #pragma unroll
@@ -132,6 +144,9 @@ __global__ __launch_bounds__(EW * 64) void energy_fwd_kernel(
         return;
     }
     const int nrows = min(TT, len - t0);
+    const float *PHb = PH + (int64_t)b * T * A;
+    float4 pf[STAGE_N];
+    stage_load(pf, PHb, t0, nrows, 0, A, vec != 0);   // in flight under the conv prologue
 
     fill_uni(uni, sp ? sp + (int64_t)b * A : nullptr, w_ee, W_fe, A);
     if (alpha_prev) {
@@ -168,12 +183,12 @@ __global__ __launch_bounds__(EW * 64) void energy_fwd_kernel(
         for (int i = threadIdx.x; i < n; i += blockDim.x) Fout[i] = Fs[i];
     }
 
-    const float *PHb = PH + (int64_t)b * T * A;
     float eacc = 0.f;
     for (int ac = 0; ac < A; ac += ACH) {
         __syncthreads();
-        stage_tile(tile, PHb, t0, nrows, ac, A, vec != 0);
+        stage_write(tile, pf);
         __syncthreads();
+        if (ac + ACH < A) stage_load(pf, PHb, t0, nrows, ac + ACH, A, vec != 0);
         const int abase = ac + wave * 16;
 #pragma unroll 4
         for (int aa = 0; aa < 16; ++aa) {
@@ -621,6 +636,9 @@ __global__ __launch_bounds__(EW * 64) void energy_bwd_kernel(
     float *tile = uni + round4(A * 12);
     float *red = tile + round4(TT * TSTR);   // [EW][64][NCH] (also used for the dot reduction)
     const int tid = threadIdx.x;
+    const float *PHb = PH + (int64_t)b * T * A;
+    float4 pf[STAGE_N];
+    stage_load(pf, PHb, t0, nrows, 0, A, vec != 0);   // in flight under the prologue
 
     // <alpha, dalpha> over the valid frames of this utterance
     float part = 0.f;
@@ -649,12 +667,12 @@ __global__ __launch_bounds__(EW * 64) void energy_bwd_kernel(
 #pragma unroll
     for (int c = 0; c < NCH; ++c) dFa[c] = 0.f;
 
-    const float *PHb = PH + (int64_t)b * T * A;
     float *dsp_out = dsp_part + ((int64_t)blockIdx.x * B + b) * A;
     for (int ac = 0; ac < A; ac += ACH) {
         __syncthreads();
-        stage_tile(tile, PHb, t0, nrows, ac, A, vec != 0);
+        stage_write(tile, pf);
         __syncthreads();
+        if (ac + ACH < A) stage_load(pf, PHb, t0, nrows, ac + ACH, A, vec != 0);
         const int abase = ac + wave * 16;
 #pragma unroll 2
         for (int aa = 0; aa < 16; ++aa) {

@@ -76,10 +76,8 @@ __global__ __launch_bounds__(256) void blstm_fwd_step_kernel(
     }
 }
 
-extern "C" int asr_blstm_fwd(const float *W_hh, float *G, float *Cs, float *Hout, int64_t ho_t,
-                             int64_t ho_b, const int32_t *lengths, int T, int B, int H, void *stream) {
-    ASR_CHECK_ARG(W_hh && G && Cs && Hout && lengths, "blstm_fwd: null pointer");
-    ASR_CHECK_ARG(T > 0 && B > 0 && H > 0, "blstm_fwd: bad shape T=%d B=%d H=%d", T, B, H);
+static int blstm_fwd_steps(const float *W_hh, float *G, float *Cs, float *Hout, int64_t ho_t,
+                          int64_t ho_b, const int32_t *lengths, int T, int B, int H, void *stream) {
     hipStream_t st = (hipStream_t)stream;
     const int vec = (H % 4 == 0) && (ho_t % 4 == 0) && (ho_b % 4 == 0) && (((uintptr_t)Hout & 15) == 0) &&
                     (((uintptr_t)W_hh & 15) == 0);
@@ -151,11 +149,9 @@ __global__ __launch_bounds__(1024) void blstm_bwd_step_kernel(
     }
 }
 
-extern "C" int asr_blstm_bwd(const float *W_hhT, float *G, const float *Cs, const float *dHout,
-                             int64_t dho_t, int64_t dho_b, const int32_t *lengths, float *dc_ws, int T,
-                             int B, int H, void *stream) {
-    ASR_CHECK_ARG(W_hhT && G && Cs && dHout && lengths && dc_ws, "blstm_bwd: null pointer");
-    ASR_CHECK_ARG(T > 0 && B > 0 && H > 0, "blstm_bwd: bad shape T=%d B=%d H=%d", T, B, H);
+static int blstm_bwd_steps(const float *W_hhT, float *G, const float *Cs, const float *dHout,
+                          int64_t dho_t, int64_t dho_b, const int32_t *lengths, float *dc_ws, int T,
+                          int B, int H, void *stream) {
     hipStream_t st = (hipStream_t)stream;
     ASR_CHECK_HIP(hipMemsetAsync(dc_ws, 0, sizeof(float) * 2 * (size_t)B * H, st));
     const int vec = (H % 4 == 0) && (((uintptr_t)G & 15) == 0) && (((uintptr_t)W_hhT & 15) == 0);
@@ -165,5 +161,366 @@ extern "C" int asr_blstm_bwd(const float *W_hhT, float *G, const float *Cs, cons
                            dho_b, lengths, dc_ws, T, B, H, step, vec);
     }
     ASR_CHECK_LAUNCH("blstm_bwd_step_kernel");
+    return ASR_OK;
+}
+
+// ===================================================== persistent kernels ==
+// One launch per layer instead of one per time step.  W_hh slices live in
+// registers for the whole sequence, the cell state c in the owner thread's
+// registers; the only data exchanged between workgroups per step is h_t
+// (forward) / dG_t (backward), handed over inside the launch:
+//   producer: write-through (sc1) stores -> every storing wave s_waitcnt
+//             vmcnt(0) -> workgroup barrier -> ONE lane stores the
+//             workgroup's flag = step+1 (sc1)
+//   consumer: wave 0 polls the group's flags with sc1 loads (relaxed, bounded
+//             spin) -> workgroup barrier -> every wave reads the payload with
+//             sc1 loads straight into the MFMA operand registers.
+// (cdna_hip_programming.md guideline 16 / MI355X_MICROARCH.md "valid forms",
+// flag row.)  The protocol does not depend on dispatch order or placement; it
+// needs all workgroups resident, which the grid guarantees by size (<= 256
+// workgroups of 256 threads, a few KB of LDS).  A poll that exceeds its spin
+// budget sets *err and makes the workgroup leave; the others then time out the
+// same way, so the grid always drains.
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+#define SPIN_LIMIT (1 << 21)
+
+__device__ __forceinline__ float4 ld4_sc1(__amdgpu_buffer_rsrc_t rsrc, int byte_off) {
+    u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, byte_off, 0, 16 /* sc1 */);
+    return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+}
+__device__ __forceinline__ void st_sc1(float *p, float v) {
+    __hip_atomic_store(reinterpret_cast<unsigned *>(p), __float_as_uint(v), __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_AGENT);
+}
+// wave-wide: wait until flags[0..n) >= want (n <= 128).  Returns false on timeout.
+__device__ __forceinline__ bool poll_flags(unsigned *flags, int n, unsigned want) {
+    const int lane = threadIdx.x & 63;
+    for (int spins = 0; spins < SPIN_LIMIT; ++spins) {
+        unsigned v0 = lane < n ? __hip_atomic_load(flags + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                               : 0xffffffffu;
+        unsigned v1 = lane + 64 < n ? __hip_atomic_load(flags + lane + 64, __ATOMIC_RELAXED,
+                                                        __HIP_MEMORY_SCOPE_AGENT)
+                                    : 0xffffffffu;
+        if (__all(v0 >= want && v1 >= want)) return true;
+        __builtin_amdgcn_s_sleep(1);
+    }
+    return false;
+}
+
+// grid (NJ = H/4, 2), block 256.  Workgroup = 4 hidden units (16 gate columns) of one
+// direction for all MT*16 batch rows.  hx[dir][parity][NJ][MT*16][4]: the h exchange.
+template <int MT, int KQ4>
+__global__ __launch_bounds__(256) void blstm_fwd_persist_kernel(
+    const float *__restrict__ W_hh, float *__restrict__ G, float *__restrict__ Cs,
+    float *__restrict__ Hout, int64_t ho_t, int64_t ho_b, const int32_t *__restrict__ lengths, int T,
+    int B, int H, float *hx, unsigned *flags, unsigned *err) {
+    __shared__ float red[4][MT][16][17];
+    __shared__ int s_abort;
+    const int jt = blockIdx.x, d = blockIdx.y, NJ = gridDim.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i = lane & 15, q = lane >> 4;
+    constexpr int KQ = KQ4 * 4;
+    const int kb = (wave * 4 + q) * KQ;
+
+    float4 wreg[KQ4];
+    {
+        const int gate = i >> 2, j = jt * 4 + (i & 3);
+        const float *wrow = W_hh + ((int64_t)d * 4 * H + gate * H + j) * H;
+#pragma unroll
+        for (int f = 0; f < KQ4; ++f) wreg[f] = (j < H && kb + 4 * f < H) ? ld4(wrow + kb + 4 * f) : zero4();
+    }
+    const bool owner = tid < MT * 64;
+    const int bi = tid >> 2, u = tid & 3;
+    const int jo = jt * 4 + u;
+    const bool valid = owner && bi < B && jo < H;
+    const int len = valid ? lengths[bi] : 0;
+    float c = 0.f;
+    const int chunk = MT * 64;                               // floats per workgroup per step
+    float *hxd = hx + (int64_t)d * 2 * NJ * chunk;
+    __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(hxd, 0, 2 * NJ * chunk * 4, 0x00020000);
+    unsigned *fl = flags + d * NJ;
+    if (tid == 0) s_abort = 0;
+    __syncthreads();
+
+    for (int s = 0; s < T; ++s) {
+        const int t = d == 0 ? s : T - 1 - s;
+        const int64_t grow = (((int64_t)t * B + bi) * 2 + d) * 4 * H;
+        float pre[4] = {0.f, 0.f, 0.f, 0.f};
+        if (valid) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) pre[g] = G[grow + g * H + jo];
+        }
+        if (s > 0) {
+            if (wave == 0) {
+                if (!poll_flags(fl, NJ, (unsigned)s)) {
+                    if (lane == 0) {
+                        s_abort = 1;
+                        __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                }
+            }
+            __syncthreads();
+            if (s_abort) break;
+            const int pbase = ((s - 1) & 1) * NJ * chunk;
+            float4 a[MT][KQ4];
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int f = 0; f < KQ4; ++f) {
+                    const int jtk = kb / 4 + f;
+                    a[m][f] = jtk < NJ ? ld4_sc1(rsrc, (pbase + jtk * chunk + (m * 16 + i) * 4) * 4) : zero4();
+                }
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int f = 0; f < KQ4; ++f) {
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m][f].x, wreg[f].x, acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m][f].y, wreg[f].y, acc1, 0, 0, 0);
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m][f].z, wreg[f].z, acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m][f].w, wreg[f].w, acc1, 0, 0, 0);
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) red[wave][m][q * 4 + r][i] = acc0[r] + acc1[r];
+            }
+            __syncthreads();
+        }
+        if (owner) {
+            float h = 0.f;
+            if (valid) {
+                float ig = 0.f, fg = 0.f, gg = 0.f, og = 0.f, cn = 0.f;
+                if (t < len) {
+                    if (s > 0) {
+                        const int m = bi >> 4, r = bi & 15;
+#pragma unroll
+                        for (int g = 0; g < 4; ++g)
+                            pre[g] += (red[0][m][r][g * 4 + u] + red[1][m][r][g * 4 + u]) +
+                                      (red[2][m][r][g * 4 + u] + red[3][m][r][g * 4 + u]);
+                    }
+                    ig = sigmoid_f(pre[0]); fg = sigmoid_f(pre[1]);
+                    gg = tanh_f(pre[2]);    og = sigmoid_f(pre[3]);
+                    cn = fg * c + ig * gg;
+                    h = og * tanh_f(cn);
+                }
+                c = cn;   // padded rows keep a zero state (reverse direction starts from it)
+                G[grow + 0 * H + jo] = ig;
+                G[grow + 1 * H + jo] = fg;
+                G[grow + 2 * H + jo] = gg;
+                G[grow + 3 * H + jo] = og;
+                Cs[(((int64_t)t * B + bi) * 2 + d) * H + jo] = cn;
+                Hout[t * ho_t + bi * ho_b + d * H + jo] = h;
+            }
+            // the 4 units of a batch row sit on 4 adjacent lanes: one 16-byte sc1 store per row
+            const float h1 = __shfl_down(h, 1, 64), h2 = __shfl_down(h, 2, 64), h3 = __shfl_down(h, 3, 64);
+            if (u == 0) {
+                u32x4 pk = {__float_as_uint(h), __float_as_uint(h1), __float_as_uint(h2), __float_as_uint(h3)};
+                __builtin_amdgcn_raw_buffer_store_b128(pk, rsrc, (((s & 1) * NJ + jt) * chunk + bi * 4) * 4, 0, 16);
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) __hip_atomic_store(fl + jt, (unsigned)(s + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+// grid (NJT = H/16, 2, NBT = ceil(B/16)), block 256: workgroup = 16 hidden units x 16 batch
+// rows of one direction.  The exchanged data is dG itself (G is overwritten in place).
+template <int KQ4>
+__global__ __launch_bounds__(256) void blstm_bwd_persist_kernel(
+    const float *__restrict__ W_hhT, float *G, const float *__restrict__ Cs,
+    const float *__restrict__ dHout, int64_t dho_t, int64_t dho_b, const int32_t *__restrict__ lengths,
+    int T, int B, int H, unsigned *flags, unsigned *err) {
+    __shared__ float red[4][16][17];
+    __shared__ __attribute__((aligned(16))) float dgl[16][4][16];
+    __shared__ int s_abort;
+    const bool vec16 = (H % 4) == 0;
+    const int jt = blockIdx.x, d = blockIdx.y, bt = blockIdx.z, NJT = gridDim.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i = lane & 15, q = lane >> 4;
+    constexpr int KQ = KQ4 * 4;
+    const int K = 4 * H;
+    const int kb = (wave * 4 + q) * KQ;
+    const int j0 = jt * 16, b0 = bt * 16;
+
+    float4 wreg[KQ4];
+    {
+        const int j = j0 + i;
+        const float *wrow = W_hhT + ((int64_t)d * H + j) * K;
+#pragma unroll
+        for (int f = 0; f < KQ4; ++f) wreg[f] = (j < H && kb + 4 * f < K) ? ld4(wrow + kb + 4 * f) : zero4();
+    }
+    const int bi = tid >> 4, ji = tid & 15;
+    const int b = b0 + bi, j = j0 + ji;
+    const bool valid = b < B && j < H;
+    const int len = valid ? lengths[b] : 0;
+    float dcarry = 0.f;
+    const bool arow = (b0 + i) < B;
+    __amdgpu_buffer_rsrc_t rsrc =
+        __builtin_amdgcn_make_buffer_rsrc(G, 0, (int)((int64_t)T * B * 8 * H * 4), 0x00020000);
+    unsigned *fl = flags + (d * gridDim.z + bt) * NJT;
+    if (tid == 0) s_abort = 0;
+    __syncthreads();
+
+    for (int s = 0; s < T; ++s) {
+        const int t = d == 0 ? T - 1 - s : s;
+        const int tn = d == 0 ? t + 1 : t - 1;   // processed in the previous step
+        const int tp = d == 0 ? t - 1 : t + 1;   // the forward pass's previous time
+        const int64_t grow = (((int64_t)t * B + b) * 2 + d) * 4 * H;
+        float ig = 0.f, fg = 0.f, gg = 0.f, og = 0.f, cc = 0.f, cp = 0.f, dh = 0.f;
+        const bool act = valid && t < len;
+        if (act) {
+            ig = G[grow + j]; fg = G[grow + H + j]; gg = G[grow + 2 * H + j]; og = G[grow + 3 * H + j];
+            cc = Cs[(((int64_t)t * B + b) * 2 + d) * H + j];
+            if (tp >= 0 && tp < T) cp = Cs[(((int64_t)tp * B + b) * 2 + d) * H + j];
+            dh = dHout[t * dho_t + b * dho_b + d * H + j];
+        }
+        if (s > 0) {
+            if (wave == 0) {
+                if (!poll_flags(fl, NJT, (unsigned)s)) {
+                    if (lane == 0) {
+                        s_abort = 1;
+                        __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                }
+            }
+            __syncthreads();
+            if (s_abort) break;
+            const int rowbase = (int)(((((int64_t)tn * B + b0 + i) * 2 + d) * 4 * H) * 4);   // bytes
+            // issue every load of this step's dG rows before the first MFMA: one memory
+            // round trip per step instead of one per chunk
+            float4 a[KQ4];
+#pragma unroll
+            for (int f = 0; f < KQ4; ++f)
+                a[f] = (arow && kb + 4 * f < K) ? ld4_sc1(rsrc, rowbase + (kb + 4 * f) * 4) : zero4();
+            f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int f = 0; f < KQ4; ++f) {
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[f].x, wreg[f].x, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[f].y, wreg[f].y, acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[f].z, wreg[f].z, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[f].w, wreg[f].w, acc1, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) red[wave][q * 4 + r][i] = acc0[r] + acc1[r];
+            __syncthreads();
+        }
+        if (valid) {
+            float d0 = 0.f, d1 = 0.f, d2 = 0.f, d3 = 0.f;
+            if (act) {
+                if (s > 0) dh += (red[0][bi][ji] + red[1][bi][ji]) + (red[2][bi][ji] + red[3][bi][ji]);
+                const float tc = tanh_f(cc);
+                const float dc = dcarry + dh * og * (1.f - tc * tc);
+                d0 = dc * gg * ig * (1.f - ig);
+                d1 = dc * cp * fg * (1.f - fg);
+                d2 = dc * ig * (1.f - gg * gg);
+                d3 = dh * tc * og * (1.f - og);
+                dcarry = dc * fg;
+            }
+            dgl[bi][0][ji] = d0; dgl[bi][1][ji] = d1; dgl[bi][2][ji] = d2; dgl[bi][3][ji] = d3;
+        }
+        __syncthreads();
+        {   // 16-byte write-through stores: thread -> (row, gate, 4 consecutive units)
+            const int g = (tid >> 2) & 3, part = tid & 3;
+            const int jj = j0 + part * 4;
+            if (b < B && jj < H) {
+                const float *src = &dgl[bi][g][part * 4];
+                const int off = (int)((grow + g * H + jj) * 4);
+                if (vec16 && jj + 3 < H) {
+                    u32x4 pk = {__float_as_uint(src[0]), __float_as_uint(src[1]), __float_as_uint(src[2]),
+                                __float_as_uint(src[3])};
+                    __builtin_amdgcn_raw_buffer_store_b128(pk, rsrc, off, 0, 16);
+                } else {
+                    for (int e = 0; e < 4 && jj + e < H; ++e) st_sc1(G + grow + g * H + jj + e, src[e]);
+                }
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) __hip_atomic_store(fl + jt, (unsigned)(s + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+// ------------------------------------------------------------ host dispatch --
+#define BLSTM_FLAG_WORDS 1024   // zeroed before every launch (multiple of 16 bytes, start of ws)
+#define BLSTM_ERR_WORD 1024     // sticky: set by a kernel whose poll timed out
+#define BLSTM_HX_OFF 2048
+
+extern "C" int64_t asr_blstm_ws_floats(int B, int H) {
+    return BLSTM_HX_OFF + (int64_t)4 * cdiv(H, 4) * cdiv(B, 16) * 64 + 64;
+}
+
+static bool al16p(const void *p) { return (((uintptr_t)p) & 15) == 0; }
+
+template <int MT>
+static bool launch_fwd_persist(int kq4, dim3 grid, hipStream_t st, const float *W_hh, float *G, float *Cs,
+                               float *Hout, int64_t ho_t, int64_t ho_b, const int32_t *lengths, int T, int B,
+                               int H, float *hx, unsigned *flags, unsigned *err) {
+#define FWD_CASE(K)                                                                                       \
+    case K:                                                                                               \
+        hipLaunchKernelGGL((blstm_fwd_persist_kernel<MT, K>), grid, dim3(256), 0, st, W_hh, G, Cs, Hout,  \
+                           ho_t, ho_b, lengths, T, B, H, hx, flags, err);                                 \
+        return true;
+    switch (kq4) {
+        FWD_CASE(1) FWD_CASE(2) FWD_CASE(3) FWD_CASE(4) FWD_CASE(5) FWD_CASE(6) FWD_CASE(7) FWD_CASE(8)
+    }
+#undef FWD_CASE
+    return false;
+}
+
+extern "C" int asr_blstm_fwd(const float *W_hh, float *G, float *Cs, float *Hout, int64_t ho_t,
+                             int64_t ho_b, const int32_t *lengths, int T, int B, int H, float *ws,
+                             void *stream) {
+    ASR_CHECK_ARG(W_hh && G && Cs && Hout && lengths, "blstm_fwd: null pointer");
+    ASR_CHECK_ARG(T > 0 && B > 0 && H > 0, "blstm_fwd: bad shape T=%d B=%d H=%d", T, B, H);
+    hipStream_t st = (hipStream_t)stream;
+    const int NJ = cdiv(H, 4), MT = cdiv(B, 16);
+    const int kq4 = (cdiv(H, 16) + 3) / 4;
+    const bool persist = ws != nullptr && H % 4 == 0 && NJ <= 128 && MT <= 2 && kq4 <= 8 && al16p(W_hh) &&
+                         al16p(ws);
+    if (!persist) return blstm_fwd_steps(W_hh, G, Cs, Hout, ho_t, ho_b, lengths, T, B, H, stream);
+    unsigned *flags = reinterpret_cast<unsigned *>(ws);
+    unsigned *err = flags + BLSTM_ERR_WORD;
+    float *hx = ws + BLSTM_HX_OFF;
+    ASR_CHECK_HIP(hipMemsetAsync(flags, 0, sizeof(unsigned) * BLSTM_FLAG_WORDS, st));
+    dim3 grid(NJ, 2);
+    bool ok = MT == 1 ? launch_fwd_persist<1>(kq4, grid, st, W_hh, G, Cs, Hout, ho_t, ho_b, lengths, T, B, H, hx,
+                                              flags, err)
+                      : launch_fwd_persist<2>(kq4, grid, st, W_hh, G, Cs, Hout, ho_t, ho_b, lengths, T, B, H, hx,
+                                              flags, err);
+    ASR_CHECK_ARG(ok, "blstm_fwd: no persistent instantiation for H=%d", H);
+    ASR_CHECK_LAUNCH("blstm_fwd_persist_kernel");
+    return ASR_OK;
+}
+
+extern "C" int asr_blstm_bwd(const float *W_hhT, float *G, const float *Cs, const float *dHout,
+                             int64_t dho_t, int64_t dho_b, const int32_t *lengths, float *dc_ws, int T,
+                             int B, int H, float *ws, void *stream) {
+    ASR_CHECK_ARG(W_hhT && G && Cs && dHout && lengths && dc_ws, "blstm_bwd: null pointer");
+    ASR_CHECK_ARG(T > 0 && B > 0 && H > 0, "blstm_bwd: bad shape T=%d B=%d H=%d", T, B, H);
+    hipStream_t st = (hipStream_t)stream;
+    const int NJT = cdiv(H, 16), NBT = cdiv(B, 16);
+    const int kq4 = (cdiv(4 * H, 16) + 3) / 4;
+    const int64_t gbytes = (int64_t)T * B * 8 * H * 4;
+    bool persist = ws != nullptr && NJT <= 128 && NJT * 2 * NBT <= 256 && 2 * NBT * NJT <= BLSTM_FLAG_WORDS &&
+                   gbytes < (int64_t)0x7fffffff && al16p(W_hhT) && al16p(G) && al16p(ws);
+    unsigned *flags = reinterpret_cast<unsigned *>(ws);
+    unsigned *err = flags ? flags + BLSTM_ERR_WORD : nullptr;
+    dim3 grid(NJT, 2, NBT);
+    if (persist) {
+        ASR_CHECK_HIP(hipMemsetAsync(flags, 0, sizeof(unsigned) * BLSTM_FLAG_WORDS, st));
+#define BWD_CASE(K)                                                                                        \
+    case K:                                                                                                \
+        hipLaunchKernelGGL((blstm_bwd_persist_kernel<K>), grid, dim3(256), 0, st, W_hhT, G, Cs, dHout,     \
+                           dho_t, dho_b, lengths, T, B, H, flags, err);                                    \
+        break;
+        switch (kq4) {
+            BWD_CASE(1) BWD_CASE(2) BWD_CASE(3) BWD_CASE(4) BWD_CASE(5) BWD_CASE(6) BWD_CASE(8) BWD_CASE(10)
+            BWD_CASE(12) BWD_CASE(16) BWD_CASE(20)
+            default: persist = false;
+        }
+#undef BWD_CASE
+    }
+    if (!persist) return blstm_bwd_steps(W_hhT, G, Cs, dHout, dho_t, dho_b, lengths, dc_ws, T, B, H, stream);
+    ASR_CHECK_LAUNCH("blstm_bwd_persist_kernel");
     return ASR_OK;
 }

@@ -13,9 +13,10 @@
 // (lane l holds A[m = l&31][k = l>>5]) without bank conflicts; global loads are
 // float4 along whichever index is contiguous in memory, prefetched into
 // registers one k-tile ahead of the MFMAs.
+#include <stdlib.h>
+
 #include "common.cuh"
 
-#define GK 16
 #define GPAD 4
 
 struct OperandView {
@@ -25,62 +26,110 @@ struct OperandView {
     int d;
 };
 
-__device__ __forceinline__ int64_t view_rowoff(const OperandView &v, int64_t i) {
-    return (i / v.d) * v.s1 + (i % v.d) * v.s0;
+// 32-bit index arithmetic: the two-level map only divides when it is really two-level
+__device__ __forceinline__ int64_t view_rowoff(const OperandView &v, int i) {
+    if (v.d == 0x7fffffff) return (int64_t)i * v.s0;
+    const int hi = i / v.d, lo = i - hi * v.d;
+    return (int64_t)hi * v.s1 + (int64_t)lo * v.s0;
 }
 
-// Load this thread's share of a (R x GK) operand tile into regs[R/64] float4s.
-//   mode 0: element (r,k) at p[rowoff(r0+r) + k];   thread f -> r = f>>2, k4 = f&3
-//   mode 1: element (r,k) at p[rowoff(k) + r0+r];   thread f -> k = f/(R/4), r4 = f%(R/4)
-template <int R>
-__device__ __forceinline__ void load_tile(const OperandView &v, int r0, int rmax, int k0, int kend,
-                                          bool vec, float4 (&regs)[R / 64]) {
-    const int tid = threadIdx.x;
+// Per-thread slots of a (R x GK) operand tile, R/64 float4s each.
+//   mode 0: element (r,k) at p[rowoff(r0+r) + k];   slot f -> r = f>>2, k4 = f&3   (row fixed per slot)
+//   mode 1: element (r,k) at p[rowoff(k) + r0+r];   slot f -> k = f/(R/4), r4 = f%(R/4)
+template <int R, int GK, int MODE, bool FAST>
+struct TileLoader {
+    static constexpr int NS = R * GK / 1024;   // float4 slots per thread
+    static constexpr int KQ = GK / 4;          // float4s per row (mode 0)
+    const float *base[NS];   // mode 0: row pointer (or null); mode 1: p + column
+    int rk[NS];              // mode 0: k offset inside the tile; mode 1: k row inside the tile
+    int rcol[NS];            // mode 1: first column of the float4
+    unsigned okmask[NS];     // FAST: all-ones if the slot of the tile in flight is in range
+
+    __device__ __forceinline__ void apply_mask(float4 (&regs)[NS]) const {
+        if (!FAST) return;
 #pragma unroll
-    for (int i = 0; i < R / 64; ++i) {
-        const int f = tid + 256 * i;
-        float4 out = zero4();
-        if (v.mode == 0) {
-            const int r = r0 + (f >> 2);
-            const int k = k0 + (f & 3) * 4;
-            if (r < rmax && k < kend) {
-                const float *src = v.p + view_rowoff(v, r) + k;
-                if (vec && k + 3 < kend) {
-                    out = ld4(src);
-                } else {
-                    out.x = src[0];
-                    if (k + 1 < kend) out.y = src[1];
-                    if (k + 2 < kend) out.z = src[2];
-                    if (k + 3 < kend) out.w = src[3];
-                }
-            }
-        } else {
-            const int k = k0 + f / (R / 4);
-            const int r = r0 + (f % (R / 4)) * 4;
-            if (k < kend && r < rmax) {
-                const float *src = v.p + view_rowoff(v, k) + r;
-                if (vec && r + 3 < rmax) {
-                    out = ld4(src);
-                } else {
-                    out.x = src[0];
-                    if (r + 1 < rmax) out.y = src[1];
-                    if (r + 2 < rmax) out.z = src[2];
-                    if (r + 3 < rmax) out.w = src[3];
-                }
+        for (int i = 0; i < NS; ++i) {
+            const unsigned m = okmask[i];
+            regs[i] = make_float4(__uint_as_float(__float_as_uint(regs[i].x) & m),
+                                  __uint_as_float(__float_as_uint(regs[i].y) & m),
+                                  __uint_as_float(__float_as_uint(regs[i].z) & m),
+                                  __uint_as_float(__float_as_uint(regs[i].w) & m));
+        }
+    }
+
+    __device__ __forceinline__ void init(const OperandView &v, int r0, int rmax) {
+        const int tid = threadIdx.x;
+#pragma unroll
+        for (int i = 0; i < NS; ++i) {
+            const int f = tid + 256 * i;
+            if (MODE == 0) {
+                const int r = r0 + f / KQ;
+                base[i] = r < rmax ? v.p + view_rowoff(v, r) : nullptr;
+                rk[i] = (f % KQ) * 4;
+                rcol[i] = 0;
+            } else {
+                const int r = r0 + (f % (R / 4)) * 4;
+                base[i] = r < rmax ? v.p + r : nullptr;
+                rk[i] = f / (R / 4);
+                rcol[i] = r;
             }
         }
-        regs[i] = out;
     }
-}
 
-template <int R>
-__device__ __forceinline__ void store_tile(int mode, float (*lds)[R + GPAD], const float4 (&regs)[R / 64]) {
+    // FAST: every float4 that starts in bounds lies fully in bounds and is 16-byte
+    // aligned (host-checked), so the loads are unconditional (out-of-range slots read a
+    // safe address and are masked to zero): no branches, all loads of a tile in flight.
+    __device__ __forceinline__ void load(const OperandView &v, int rmax, int k0, int kend, bool vec,
+                                         float4 (&regs)[NS]) {
+#pragma unroll
+        for (int i = 0; i < NS; ++i) {
+            const int k = k0 + rk[i];
+            if (FAST) {
+                const bool ok = base[i] != nullptr && k < kend;
+                const float *src = MODE == 0 ? base[i] + k : base[i] + view_rowoff(v, k);
+                src = ok ? src : v.p;
+                regs[i] = ld4(src);      // masked to zero later, in apply_mask (after the MFMAs)
+                okmask[i] = ok ? 0xffffffffu : 0u;
+                continue;
+            }
+            float4 out = zero4();
+            if (base[i] != nullptr && k < kend) {
+                if (MODE == 0) {
+                    const float *src = base[i] + k;
+                    if (vec && k + 3 < kend) {
+                        out = ld4(src);
+                    } else {
+                        out.x = src[0];
+                        if (k + 1 < kend) out.y = src[1];
+                        if (k + 2 < kend) out.z = src[2];
+                        if (k + 3 < kend) out.w = src[3];
+                    }
+                } else {
+                    const float *src = base[i] + view_rowoff(v, k);
+                    const int r = rcol[i];
+                    if (vec && r + 3 < rmax) {
+                        out = ld4(src);
+                    } else {
+                        out.x = src[0];
+                        if (r + 1 < rmax) out.y = src[1];
+                        if (r + 2 < rmax) out.z = src[2];
+                        if (r + 3 < rmax) out.w = src[3];
+                    }
+                }
+            }
+            regs[i] = out;
+        }
+    }
+};
+
+template <int R, int GK, int MODE>
+__device__ __forceinline__ void store_tile(float (*lds)[R + GPAD], const float4 (&regs)[R * GK / 1024]) {
     const int tid = threadIdx.x;
 #pragma unroll
-    for (int i = 0; i < R / 64; ++i) {
+    for (int i = 0; i < R * GK / 1024; ++i) {
         const int f = tid + 256 * i;
-        if (mode == 0) {
-            const int r = f >> 2, k = (f & 3) * 4;
+        if (MODE == 0) {
+            const int r = f / (GK / 4), k = (f % (GK / 4)) * 4;
             lds[k + 0][r] = regs[i].x;
             lds[k + 1][r] = regs[i].y;
             lds[k + 2][r] = regs[i].z;
@@ -92,7 +141,7 @@ __device__ __forceinline__ void store_tile(int mode, float (*lds)[R + GPAD], con
     }
 }
 
-template <int BM, int BN>
+template <int BM, int BN, int GK, int AMODE, int BMODE, bool FAST>
 __global__ __launch_bounds__(256) void sgemm_kernel(asr_gemm_desc d, int vecA, int vecB, int ktiles_per_split) {
     constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
     __shared__ __attribute__((aligned(16))) float As[2][GK][BM + GPAD];
@@ -119,12 +168,18 @@ __global__ __launch_bounds__(256) void sgemm_kernel(asr_gemm_desc d, int vecA, i
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    float4 ra[BM / 64], rb[BN / 64];
+    float4 ra[BM * GK / 1024], rb[BN * GK / 1024];
+    TileLoader<BM, GK, AMODE, FAST> la;
+    TileLoader<BN, GK, BMODE, FAST> lb;
+    la.init(va, m0, d.M);
+    lb.init(vb, n0, d.N);
     if (nk > 0) {
-        load_tile<BM>(va, m0, d.M, kbeg, kend, vecA, ra);
-        load_tile<BN>(vb, n0, d.N, kbeg, kend, vecB, rb);
-        store_tile<BM>(va.mode, As[0], ra);
-        store_tile<BN>(vb.mode, Bs[0], rb);
+        la.load(va, d.M, kbeg, kend, vecA, ra);
+        lb.load(vb, d.N, kbeg, kend, vecB, rb);
+        la.apply_mask(ra);
+        lb.apply_mask(rb);
+        store_tile<BM, GK, AMODE>(As[0], ra);
+        store_tile<BN, GK, BMODE>(Bs[0], rb);
     }
     __syncthreads();
 
@@ -132,8 +187,8 @@ __global__ __launch_bounds__(256) void sgemm_kernel(asr_gemm_desc d, int vecA, i
     for (int kt = 0; kt < nk; ++kt) {
         const bool more = kt + 1 < nk;
         if (more) {
-            load_tile<BM>(va, m0, d.M, kbeg + (kt + 1) * GK, kend, vecA, ra);
-            load_tile<BN>(vb, n0, d.N, kbeg + (kt + 1) * GK, kend, vecB, rb);
+            la.load(va, d.M, kbeg + (kt + 1) * GK, kend, vecA, ra);
+            lb.load(vb, d.N, kbeg + (kt + 1) * GK, kend, vecB, rb);
         }
         const int kh = lane >> 5, l31 = lane & 31;
 #pragma unroll
@@ -150,8 +205,11 @@ __global__ __launch_bounds__(256) void sgemm_kernel(asr_gemm_desc d, int vecA, i
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
         }
         if (more) {
-            store_tile<BM>(va.mode, As[cur ^ 1], ra);
-            store_tile<BN>(vb.mode, Bs[cur ^ 1], rb);
+            __builtin_amdgcn_sched_barrier(0);   // keep the wait for the prefetched tile behind the MFMAs
+            la.apply_mask(ra);
+            lb.apply_mask(rb);
+            store_tile<BM, GK, AMODE>(As[cur ^ 1], ra);
+            store_tile<BN, GK, BMODE>(Bs[cur ^ 1], rb);
         }
         __syncthreads();
         cur ^= 1;
@@ -159,8 +217,15 @@ __global__ __launch_bounds__(256) void sgemm_kernel(asr_gemm_desc d, int vecA, i
 
     // epilogue: C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
     const bool first = (split == 0);
+    OperandView vc{nullptr, 0, d.c_s0, d.c_s1, d.c_d};
 #pragma unroll
-    for (int i = 0; i < TM; ++i)
+    for (int i = 0; i < TM; ++i) {
+        int64_t coff[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            coff[r] = row < d.M ? view_rowoff(vc, row) : -1;
+        }
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             const int col = n0 + wn * WN + j * 32 + (lane & 31);
@@ -172,9 +237,8 @@ __global__ __launch_bounds__(256) void sgemm_kernel(asr_gemm_desc d, int vecA, i
             }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int row = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                if (row >= d.M) continue;
-                float *dst = C + rowoff2(row, d.c_d, d.c_s0, d.c_s1) + col;
+                if (coff[r] < 0) continue;
+                float *dst = C + coff[r] + col;
                 float v = d.alpha * acc[i][j][r] + bias;
                 if (d.splitk > 1) {
                     atomicAdd(dst, v);
@@ -185,6 +249,7 @@ __global__ __launch_bounds__(256) void sgemm_kernel(asr_gemm_desc d, int vecA, i
                 }
             }
         }
+    }
 }
 
 static bool aligned16(const void *p) { return (((uintptr_t)p) & 15) == 0; }
@@ -211,6 +276,18 @@ extern "C" int asr_sgemm(const asr_gemm_desc *din, void *stream) {
     const int vecA = aligned16(d.A) && strides_ok(d.a_s0, d.a_s1, d.nbatch > 1 ? d.batch_a : 0);
     const int vecB = aligned16(d.B) && strides_ok(d.b_s0, d.b_s1, d.nbatch > 1 ? d.batch_b : 0);
 
+    const int64_t tiles128 = (int64_t)cdiv(d.M, 128) * cdiv(d.N, 128) * d.nbatch * (d.splitk > 0 ? d.splitk : 1);
+    const bool big = d.M >= 128 && d.N >= 128 && tiles128 >= 128;
+    static int gk_big = 0;
+    if (gk_big == 0) {
+        const char *e = getenv("ASR_GEMM_GK");
+        gk_big = (e && atoi(e) == 32) ? 32 : 16;
+    }
+    // fast path: 16-byte aligned operands whose contiguous extent is a multiple of 4
+    const bool fastA = vecA && (d.a_mode == 0 ? d.K % 4 == 0 : d.M % 4 == 0);
+    const bool fastB = vecB && (d.b_mode == 0 ? d.K % 4 == 0 : d.N % 4 == 0);
+    const bool fast = fastA && fastB;
+    const int GK = (big && fast) ? gk_big : 16;
     const int ktiles = cdiv(d.K, GK);
     int splitk = d.splitk;
     if (splitk > ktiles) splitk = ktiles > 0 ? ktiles : 1;
@@ -218,17 +295,29 @@ extern "C" int asr_sgemm(const asr_gemm_desc *din, void *stream) {
     const int per = ktiles > 0 ? cdiv(ktiles, splitk) : 0;
 
     hipStream_t st = (hipStream_t)stream;
-    const int64_t big_tiles = (int64_t)cdiv(d.M, 128) * cdiv(d.N, 128) * d.nbatch * splitk;
-    const bool big = d.M >= 128 && d.N >= 128 && big_tiles >= 192;
+    const int sel = d.a_mode * 2 + d.b_mode;
+#define LAUNCH(BM_, BN_, GK_, AM, BM2, F)                                                              \
+    hipLaunchKernelGGL((sgemm_kernel<BM_, BN_, GK_, AM, BM2, F>), grid, dim3(256), 0, st, d, vecA, vecB, per)
+#define LAUNCH_MODES(BM_, BN_, GK_, F)                    \
+    switch (sel) {                                        \
+        case 0: LAUNCH(BM_, BN_, GK_, 0, 0, F); break;    \
+        case 1: LAUNCH(BM_, BN_, GK_, 0, 1, F); break;    \
+        case 2: LAUNCH(BM_, BN_, GK_, 1, 0, F); break;    \
+        default: LAUNCH(BM_, BN_, GK_, 1, 1, F); break;   \
+    }
     if (big) {
         dim3 grid(cdiv(d.N, 128), cdiv(d.M, 128), d.nbatch * splitk);
         ASR_CHECK_ARG(grid.y <= 65535 && grid.z <= 65535, "sgemm: grid too large");
-        hipLaunchKernelGGL((sgemm_kernel<128, 128>), grid, dim3(256), 0, st, d, vecA, vecB, per);
+        if (fast && GK == 32) { LAUNCH_MODES(128, 128, 32, true) }
+        else if (fast) { LAUNCH_MODES(128, 128, 16, true) }
+        else { LAUNCH_MODES(128, 128, 16, false) }
     } else {
         dim3 grid(cdiv(d.N, 64), cdiv(d.M, 64), d.nbatch * splitk);
         ASR_CHECK_ARG(grid.y <= 65535 && grid.z <= 65535, "sgemm: grid too large");
-        hipLaunchKernelGGL((sgemm_kernel<64, 64>), grid, dim3(256), 0, st, d, vecA, vecB, per);
+        if (fast) { LAUNCH_MODES(64, 64, 16, true) } else { LAUNCH_MODES(64, 64, 16, false) }
     }
+#undef LAUNCH_MODES
+#undef LAUNCH
     ASR_CHECK_LAUNCH("sgemm_kernel");
     return ASR_OK;
 }

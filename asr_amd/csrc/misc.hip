@@ -100,45 +100,41 @@ __global__ __launch_bounds__(256) void scatter_rows_kernel(const float *__restri
                                                            const int64_t *__restrict__ idx, int n_rows,
                                                            int width, int64_t src_stride,
                                                            float *__restrict__ table) {
-    __shared__ int hits[256];
+    // one pass over the index list collects this row's hits, a parallel rank sort
+    // restores ascending order, then the block sums the hit rows.
+    constexpr int MAXH = 1024;
+    __shared__ int hits[MAXH];
+    __shared__ int sorted[MAXH];
     __shared__ int nhit;
     const int v = blockIdx.x;
     float *dst = table + (int64_t)v * width;
-    for (int c0 = 0; c0 < width; c0 += 256 * 8) {
-        float acc[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) acc[u] = 0.f;
-        for (int base = 0; base < n_rows; base += 256) {
-            __syncthreads();
-            if (threadIdx.x == 0) nhit = 0;
-            __syncthreads();
-            const int i = base + threadIdx.x;
-            if (i < n_rows && idx[i] == v) hits[atomicAdd(&nhit, 1)] = i;
-            __syncthreads();
-            const int n = nhit;
-            // deterministic order: sort the (few) hits of this chunk by row index
-            if (threadIdx.x == 0 && n > 1) {
-                for (int a = 1; a < n; ++a) {
-                    int key = hits[a], p = a - 1;
-                    while (p >= 0 && hits[p] > key) { hits[p + 1] = hits[p]; --p; }
-                    hits[p + 1] = key;
-                }
-            }
-            __syncthreads();
-            for (int h = 0; h < n; ++h) {
-                const float *row = src + (int64_t)hits[h] * src_stride;
-#pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    int c = c0 + u * 256 + threadIdx.x;
-                    if (c < width) acc[u] += row[c];
-                }
-            }
+    if (threadIdx.x == 0) nhit = 0;
+    __syncthreads();
+    for (int i = threadIdx.x; i < n_rows; i += 256)
+        if (idx[i] == v) {
+            const int slot = atomicAdd(&nhit, 1);
+            if (slot < MAXH) hits[slot] = i;
         }
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            int c = c0 + u * 256 + threadIdx.x;
-            if (c < width) dst[c] = acc[u];
+    __syncthreads();
+    const int total = nhit;
+    const int n = total < MAXH ? total : MAXH;
+    // restore ascending row order (deterministic sum): rank = number of smaller hits
+    for (int a = threadIdx.x; a < n; a += 256) {
+        const int key = hits[a];
+        int rank = 0;
+        for (int o = 0; o < n; ++o) rank += hits[o] < key;
+        sorted[rank] = key;
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < width; c += 256) {
+        float acc = 0.f;
+        if (total <= MAXH) {
+            for (int h = 0; h < n; ++h) acc += src[(int64_t)sorted[h] * src_stride + c];
+        } else {   // a label repeated more than MAXH times: plain ordered scan
+            for (int i = 0; i < n_rows; ++i)
+                if (idx[i] == v) acc += src[(int64_t)i * src_stride + c];
         }
+        dst[c] = acc;
     }
 }
 

@@ -64,13 +64,16 @@ def sgemm(A, B, Cm, M, N, K, *, a_mode=0, b_mode=0, a_stride=None, b_stride=None
 
 
 def pick_splitk(M, N, K, nbatch=1):
-    """Split K until the launch has roughly one wave of 64x64..128x128 tiles per CU."""
-    tiles = ((M + 127) // 128) * ((N + 127) // 128) * nbatch
-    if tiles >= 192 or K < 512:
+    """Split K over workgroups until the launch has about three 128x128 tiles per CU
+    (weight gradients: small M x N, K = all frames of the batch)."""
+    if M < 128 or N < 128:
+        tiles = ((M + 63) // 64) * ((N + 63) // 64) * nbatch
+    else:
+        tiles = ((M + 127) // 128) * ((N + 127) // 128) * nbatch
+    if tiles >= 256 or K < 512:
         return 1
-    tiles64 = ((M + 63) // 64) * ((N + 63) // 64) * nbatch
-    want = max(1, 512 // max(tiles64, 1))
-    return int(max(1, min(want, K // 128, 64)))
+    want = (768 + tiles - 1) // tiles
+    return int(max(1, min(want, K // 512, 64)))
 
 
 def linear_nt(x2d, W, out2d, bias1=None, bias2=None, act=0, accumulate=False):

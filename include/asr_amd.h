@@ -121,10 +121,15 @@ int asr_scale(float *x, int64_t n, float s, void *stream);
  *   Hout  element (t,b,dir*H+j) at t*ho_t + b*ho_b + dir*H + j   (2H wide rows)
  *   W_hh  [2][4H][H]   (dir 0 = weight_hh_l{k}, dir 1 = weight_hh_l{k}_reverse)
  *   lengths (B) int32 on device
+ *   ws    asr_blstm_ws_floats(B,H) floats, 16-byte aligned, ZERO on first use: flag
+ *         words + the h exchange of the persistent (one launch per layer) kernels;
+ *         word 1024 is a sticky error word a kernel sets if an in-launch wait
+ *         timed out.  ws == NULL selects the one-launch-per-time-step kernels.
  */
+int64_t asr_blstm_ws_floats(int B, int H);
 int asr_blstm_fwd(const float *W_hh, float *G, float *Cs, float *Hout,
                   int64_t ho_t, int64_t ho_b, const int32_t *lengths,
-                  int T, int B, int H, void *stream);
+                  int T, int B, int H, float *ws, void *stream);
 
 /* Backward of the recurrence.
  *   W_hhT [2][H][4H]   transposed recurrent weights (asr_transpose)
@@ -135,7 +140,7 @@ int asr_blstm_fwd(const float *W_hh, float *G, float *Cs, float *Hout,
  */
 int asr_blstm_bwd(const float *W_hhT, float *G, const float *Cs, const float *dHout,
                   int64_t dho_t, int64_t dho_b, const int32_t *lengths,
-                  float *dc_ws, int T, int B, int H, void *stream);
+                  float *dc_ws, int T, int B, int H, float *ws, void *stream);
 
 /* inverted dropout between encoder layers (nn.LSTM dropout=, Models/encoder.py:26):
  * y = x * mask / (1-p), mask ~ Bernoulli(1-p) from a counter-based hash of

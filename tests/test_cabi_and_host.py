@@ -35,7 +35,7 @@ def test_bad_arguments_are_reported_not_thrown():
     rc = lib.asr_ls_ce_fwd_bwd(0, 0, 0, 1, 1, 2, 0.1, 1, 0, 0, 0, 0, 0)
     assert rc == -1
     assert b"null" in lib.asr_last_error()
-    rc = lib.asr_blstm_fwd(0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 0)
+    rc = lib.asr_blstm_fwd(0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 0, 0)
     assert rc == -1
     with pytest.raises(RuntimeError):
         _lib.check(rc)

@@ -150,6 +150,44 @@ def test_blstm_vs_oracle(B, T, D, H, N, lens):
     assert rel_err(xd.grad.cpu(), xr.grad) < GRAD_TOL
     for (k, p), (_, q) in zip(enc.named_parameters(), ref.named_parameters()):
         assert rel_err(p.grad.cpu(), q.grad) < GRAD_TOL, k
+    from asr_amd.Models.encoder import persistent_error_flags
+    assert not persistent_error_flags()
+
+
+def test_persistent_and_stepwise_recurrence_agree():
+    """The one-launch-per-layer (in-launch hand-off) kernels against the
+    one-launch-per-time-step kernels at the production width, ragged batch of 32;
+    also checks that no in-launch wait ever timed out."""
+    from asr_amd.Models import encoder as E
+    from oracle import ref_model as R
+    dev = _dev()
+    hp = R.make_hp(lmfb_dim=40, frame_stacking=1, num_hidden_nodes=320, num_encoder_layer=2, encoder_dropout=0.0)
+    torch.manual_seed(77)
+    enc = E.Encoder(hp).to(dev).train()
+    B, T = 32, 70
+    lengths = torch.linspace(T, 20, B).long()
+    x = torch.randn(B, T, 40)
+    for b in range(B):
+        x[b, lengths[b]:] = 0
+    w = torch.randn(B, T, 640, device=dev)
+    outs = []
+    for persistent in (True, False):
+        E.PERSISTENT = persistent
+        try:
+            for p in enc.parameters():
+                p.grad = None
+            xd = x.to(dev).requires_grad_(True)
+            h = enc(xd, lengths)
+            (h * w).sum().backward()
+            outs.append((h.detach().cpu(), xd.grad.cpu(), [p.grad.cpu() for p in enc.parameters()]))
+        finally:
+            E.PERSISTENT = True
+    (h1, dx1, g1), (h2, dx2, g2) = outs
+    assert rel_err(h1, h2) < 1e-6
+    assert rel_err(dx1, dx2) < 1e-5
+    for a, b_ in zip(g1, g2):
+        assert rel_err(a, b_) < 1e-5
+    assert not E.persistent_error_flags()
 
 
 @pytest.mark.parametrize("B,T,He,Hd,V,L,lens", [(3, 17, 8, 8, 11, 5, [17, 9, 4]), (4, 70, 6, 10, 13, 6, [70, 64, 65, 1]),
