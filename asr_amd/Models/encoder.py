@@ -125,9 +125,10 @@ class _BLSTMLayerFunction(torch.autograd.Function):
         dHout = dHout.contiguous()                 # same layout as Hout
         f32 = dict(device=dev, dtype=torch.float32)
         dc_ws = torch.empty(2 * B * H, **f32)
-        W_hhT = ops.transpose(torch.cat([w_hh_f, w_hh_r], 0).view(2, 4 * H, H))   # [2][H][4H]
+        W_hh = torch.cat([w_hh_f, w_hh_r], 0).view(2, 4 * H, H)
+        W_hhT = ops.transpose(W_hh)                # [2][H][4H] (step-wise kernels)
         ws = _persist_ws(lib, B, H, dev)
-        check(lib.asr_blstm_bwd(W_hhT.data_ptr(), G.data_ptr(), Cs.data_ptr(), dHout.data_ptr(), ho_t, ho_b,
+        check(lib.asr_blstm_bwd(W_hh.data_ptr(), W_hhT.data_ptr(), G.data_ptr(), Cs.data_ptr(), dHout.data_ptr(), ho_t, ho_b,
                                 lengths_dev.data_ptr(), dc_ws.data_ptr(), T, B, H,
                                 0 if ws is None else ws.data_ptr(), st))
         dG = G.view(T * B, 8 * H)                  # now d loss / d pre-activation gates (0 at padding)

@@ -58,6 +58,7 @@ class AttDecBwdArgs(C.Structure):
 SYMBOLS = {
     "asr_version": (C.c_int, []),
     "asr_last_error": (C.c_char_p, []),
+    "asr_debug_set": (None, [C.c_int]),
     "asr_ls_ce_fwd_bwd": (C.c_int, [c_f, c_f, c_f, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int,
                                     c_f, c_f, c_f, c_f]),
     "asr_sgemm": (C.c_int, [C.POINTER(GemmDesc), c_f]),
@@ -69,8 +70,8 @@ SYMBOLS = {
     "asr_scale": (C.c_int, [c_f, c_i64, C.c_float, c_f]),
     "asr_blstm_ws_floats": (c_i64, [C.c_int, C.c_int]),
     "asr_blstm_fwd": (C.c_int, [c_f, c_f, c_f, c_f, c_i64, c_i64, c_f, C.c_int, C.c_int, C.c_int, c_f, c_f]),
-    "asr_blstm_bwd": (C.c_int, [c_f, c_f, c_f, c_f, c_i64, c_i64, c_f, c_f, C.c_int, C.c_int, C.c_int, c_f,
-                                c_f]),
+    "asr_blstm_bwd": (C.c_int, [c_f, c_f, c_f, c_f, c_f, c_i64, c_i64, c_f, c_f, C.c_int, C.c_int, C.c_int,
+                                c_f, c_f]),
     "asr_dropout_fwd": (C.c_int, [c_f, c_f, c_f, c_i64, C.c_float, C.c_uint64, c_f]),
     "asr_dropout_bwd": (C.c_int, [c_f, c_f, c_f, c_i64, C.c_float, c_f]),
     "asr_attdec_ws_floats": (c_i64, [C.c_int] * 5),

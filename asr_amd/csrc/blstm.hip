@@ -183,6 +183,7 @@ static int blstm_bwd_steps(const float *W_hhT, float *G, const float *Cs, const 
 // same way, so the grid always drains.
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 #define SPIN_LIMIT (1 << 21)
+#define OOB_OFF 0x7ffffff0   // beyond every buffer here: the range check returns zeros
 
 __device__ __forceinline__ float4 ld4_sc1(__amdgpu_buffer_rsrc_t rsrc, int byte_off) {
     u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, byte_off, 0, 16 /* sc1 */);
@@ -191,6 +192,12 @@ __device__ __forceinline__ float4 ld4_sc1(__amdgpu_buffer_rsrc_t rsrc, int byte_
 __device__ __forceinline__ void st_sc1(float *p, float v) {
     __hip_atomic_store(reinterpret_cast<unsigned *>(p), __float_as_uint(v), __ATOMIC_RELAXED,
                        __HIP_MEMORY_SCOPE_AGENT);
+}
+// epoch tag carried in the mantissa LSB of every exchanged float (tag mode)
+__device__ __forceinline__ unsigned tag_bits(float v, unsigned e) { return (__float_as_uint(v) & ~1u) | e; }
+__device__ __forceinline__ bool tags_ok(const float4 &v, unsigned e) {
+    return (((__float_as_uint(v.x) ^ e) | (__float_as_uint(v.y) ^ e) | (__float_as_uint(v.z) ^ e) |
+             (__float_as_uint(v.w) ^ e)) & 1u) == 0u;
 }
 // wave-wide: wait until flags[0..n) >= want (n <= 128).  Returns false on timeout.
 __device__ __forceinline__ bool poll_flags(unsigned *flags, int n, unsigned want) {
@@ -213,8 +220,8 @@ template <int MT, int KQ4>
 __global__ __launch_bounds__(256) void blstm_fwd_persist_kernel(
     const float *__restrict__ W_hh, float *__restrict__ G, float *__restrict__ Cs,
     float *__restrict__ Hout, int64_t ho_t, int64_t ho_b, const int32_t *__restrict__ lengths, int T,
-    int B, int H, float *hx, unsigned *flags, unsigned *err) {
-    __shared__ float red[4][MT][16][17];
+    int B, int H, float *hx, unsigned *flags, unsigned *err, int dbg, int tagmode) {
+    __shared__ float red[2][4][MT][16][17];
     __shared__ int s_abort;
     const int jt = blockIdx.x, d = blockIdx.y, NJ = gridDim.x;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -251,25 +258,43 @@ __global__ __launch_bounds__(256) void blstm_fwd_persist_kernel(
             for (int g = 0; g < 4; ++g) pre[g] = G[grow + g * H + jo];
         }
         if (s > 0) {
-            if (wave == 0) {
-                if (!poll_flags(fl, NJ, (unsigned)s)) {
+            if (!tagmode) {
+                if (wave == 0 && !(dbg & 1)) {
+                    if (!poll_flags(fl, NJ, (unsigned)s)) {
+                        if (lane == 0) {
+                            s_abort = 1;
+                            __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        }
+                    }
+                }
+                __syncthreads();
+                if (s_abort) break;
+            }
+            const int pbase = ((s - 1) & 1) * NJ * chunk;
+            float4 a[MT][KQ4];
+            const unsigned want = (unsigned)(((s - 1) >> 1) & 1);
+            for (int spins = 0;; ++spins) {
+                bool ok = true;
+#pragma unroll
+                for (int m = 0; m < MT; ++m)
+#pragma unroll
+                    for (int f = 0; f < KQ4; ++f) {
+                        // branch-free: an out-of-range offset makes the buffer load return zeros
+                        const int jtk = kb / 4 + f;
+                        const bool in = jtk < NJ;
+                        a[m][f] = ld4_sc1(rsrc, in ? (pbase + jtk * chunk + (m * 16 + i) * 4) * 4 : OOB_OFF);
+                        ok = ok & (tags_ok(a[m][f], want) | !in);
+                    }
+                if (!tagmode || (dbg & 1) || __all(ok)) break;   // wave-uniform
+                if (spins >= SPIN_LIMIT) {
                     if (lane == 0) {
                         s_abort = 1;
                         __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     }
+                    break;
                 }
+                __builtin_amdgcn_s_sleep(1);
             }
-            __syncthreads();
-            if (s_abort) break;
-            const int pbase = ((s - 1) & 1) * NJ * chunk;
-            float4 a[MT][KQ4];
-#pragma unroll
-            for (int m = 0; m < MT; ++m)
-#pragma unroll
-                for (int f = 0; f < KQ4; ++f) {
-                    const int jtk = kb / 4 + f;
-                    a[m][f] = jtk < NJ ? ld4_sc1(rsrc, (pbase + jtk * chunk + (m * 16 + i) * 4) * 4) : zero4();
-                }
 #pragma unroll
             for (int m = 0; m < MT; ++m) {
                 f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
@@ -281,9 +306,10 @@ __global__ __launch_bounds__(256) void blstm_fwd_persist_kernel(
                     acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m][f].w, wreg[f].w, acc1, 0, 0, 0);
                 }
 #pragma unroll
-                for (int r = 0; r < 4; ++r) red[wave][m][q * 4 + r][i] = acc0[r] + acc1[r];
+                for (int r = 0; r < 4; ++r) red[s & 1][wave][m][q * 4 + r][i] = acc0[r] + acc1[r];
             }
             __syncthreads();
+            if (s_abort) break;
         }
         if (owner) {
             float h = 0.f;
@@ -294,8 +320,8 @@ __global__ __launch_bounds__(256) void blstm_fwd_persist_kernel(
                         const int m = bi >> 4, r = bi & 15;
 #pragma unroll
                         for (int g = 0; g < 4; ++g)
-                            pre[g] += (red[0][m][r][g * 4 + u] + red[1][m][r][g * 4 + u]) +
-                                      (red[2][m][r][g * 4 + u] + red[3][m][r][g * 4 + u]);
+                            pre[g] += (red[s & 1][0][m][r][g * 4 + u] + red[s & 1][1][m][r][g * 4 + u]) +
+                                      (red[s & 1][2][m][r][g * 4 + u] + red[s & 1][3][m][r][g * 4 + u]);
                     }
                     ig = sigmoid_f(pre[0]); fg = sigmoid_f(pre[1]);
                     gg = tanh_f(pre[2]);    og = sigmoid_f(pre[3]);
@@ -312,14 +338,21 @@ __global__ __launch_bounds__(256) void blstm_fwd_persist_kernel(
             }
             // the 4 units of a batch row sit on 4 adjacent lanes: one 16-byte sc1 store per row
             const float h1 = __shfl_down(h, 1, 64), h2 = __shfl_down(h, 2, 64), h3 = __shfl_down(h, 3, 64);
-            if (u == 0) {
+            if (u == 0 && !(dbg & 8)) {
                 u32x4 pk = {__float_as_uint(h), __float_as_uint(h1), __float_as_uint(h2), __float_as_uint(h3)};
+                if (tagmode) {
+                    const unsigned e = (unsigned)((s >> 1) & 1);
+                    pk = u32x4{tag_bits(h, e), tag_bits(h1, e), tag_bits(h2, e), tag_bits(h3, e)};
+                }
                 __builtin_amdgcn_raw_buffer_store_b128(pk, rsrc, (((s & 1) * NJ + jt) * chunk + bi * 4) * 4, 0, 16);
             }
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (tid == 0) __hip_atomic_store(fl + jt, (unsigned)(s + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (!tagmode) {
+            if (!(dbg & 2)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (tid == 0)
+                __hip_atomic_store(fl + jt, (unsigned)(s + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
     }
 }
 
@@ -329,7 +362,7 @@ template <int KQ4>
 __global__ __launch_bounds__(256) void blstm_bwd_persist_kernel(
     const float *__restrict__ W_hhT, float *G, const float *__restrict__ Cs,
     const float *__restrict__ dHout, int64_t dho_t, int64_t dho_b, const int32_t *__restrict__ lengths,
-    int T, int B, int H, unsigned *flags, unsigned *err) {
+    int T, int B, int H, unsigned *flags, unsigned *err, int dbg) {
     __shared__ float red[4][16][17];
     __shared__ __attribute__((aligned(16))) float dgl[16][4][16];
     __shared__ int s_abort;
@@ -375,7 +408,7 @@ __global__ __launch_bounds__(256) void blstm_bwd_persist_kernel(
             dh = dHout[t * dho_t + b * dho_b + d * H + j];
         }
         if (s > 0) {
-            if (wave == 0) {
+            if (wave == 0 && !(dbg & 1)) {
                 if (!poll_flags(fl, NJT, (unsigned)s)) {
                     if (lane == 0) {
                         s_abort = 1;
@@ -391,7 +424,7 @@ __global__ __launch_bounds__(256) void blstm_bwd_persist_kernel(
             float4 a[KQ4];
 #pragma unroll
             for (int f = 0; f < KQ4; ++f)
-                a[f] = (arow && kb + 4 * f < K) ? ld4_sc1(rsrc, rowbase + (kb + 4 * f) * 4) : zero4();
+                a[f] = ld4_sc1(rsrc, (arow && kb + 4 * f < K) ? rowbase + (kb + 4 * f) * 4 : OOB_OFF);
             f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int f = 0; f < KQ4; ++f) {
@@ -422,7 +455,7 @@ __global__ __launch_bounds__(256) void blstm_bwd_persist_kernel(
         {   // 16-byte write-through stores: thread -> (row, gate, 4 consecutive units)
             const int g = (tid >> 2) & 3, part = tid & 3;
             const int jj = j0 + part * 4;
-            if (b < B && jj < H) {
+            if (b < B && jj < H && !(dbg & 8)) {
                 const float *src = &dgl[bi][g][part * 4];
                 const int off = (int)((grow + g * H + jj) * 4);
                 if (vec16 && jj + 3 < H) {
@@ -434,9 +467,193 @@ __global__ __launch_bounds__(256) void blstm_bwd_persist_kernel(
                 }
             }
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (!(dbg & 2)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (tid == 0) __hip_atomic_store(fl + jt, (unsigned)(s + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+// Backward recurrence, reduce-scatter form.  A workgroup owns UW hidden units (all four
+// gates: KL = 4*UW rows of W_hh) of 16 batch rows.  After its cell backward it holds
+// dG_t for those rows locally (LDS) and multiplies it with ITS rows of W_hh:
+//     P[b][j] = sum_{n in own rows} dG_t[b][n] W_hh[n][j]      for ALL j   (M = j, N = b, K = KL)
+// with W_hh's rows resident in registers for the whole sequence.  The partial products
+// are handed to the other workgroups of the (direction, batch tile) group through
+// xP[dir][bt][parity][src][H/16][16 rows][16 units] (every store instruction of a wave
+// writes whole 128-byte lines); the owner of unit j sums the NJT partials in a
+// fixed order (deterministic).  Compared with exchanging dG itself this moves
+// 16*H*4 B out and in per workgroup and step instead of 16*4H*4 B in, and the
+// MFMA operands never come from another workgroup.
+template <int UW, int NMT>
+__global__ __launch_bounds__(256) void blstm_bwd_rs_kernel(
+    const float *__restrict__ W_hh, float *__restrict__ G, const float *__restrict__ Cs,
+    const float *__restrict__ dHout, int64_t dho_t, int64_t dho_b, const int32_t *__restrict__ lengths,
+    int T, int B, int H, float *xP, unsigned *flags, unsigned *err, int dbg, int tagmode) {
+    constexpr int KL = 4 * UW, KS = KL / 4, DSTR = KL + 4;
+    constexpr int NI = 16 * UW / 4;     // 16-byte items per source workgroup (16 rows x UW/4)
+    constexpr int NG = 256 / NI;        // thread groups that split the sources
+    __shared__ float dgl[16][DSTR];
+    __shared__ __attribute__((aligned(16))) float part[NG][NI][4];
+    __shared__ int s_abort;
+    const int jt = blockIdx.x, d = blockIdx.y, bt = blockIdx.z, NJT = gridDim.x, NBT = gridDim.z;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i = lane & 15, q = lane >> 4;
+    const int j0 = jt * UW, b0 = bt * 16;
+    const int MTILES = (H + 15) / 16, Hp = MTILES * 16;
+
+    // A operand: W_hh[own row k][j = 16*mt + i], k = 4*ks + q  (resident for all T steps)
+    float areg[NMT][KS];
+#pragma unroll
+    for (int mtl = 0; mtl < NMT; ++mtl) {
+        const int jc = 16 * (wave + 4 * mtl) + i;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const int k = 4 * ks + q;
+            const int g = k / UW, ju = k % UW;
+            const bool ok = jc < H && j0 + ju < H;
+            areg[mtl][ks] = ok ? W_hh[((int64_t)d * 4 * H + g * H + j0 + ju) * H + jc] : 0.f;
+        }
+    }
+    const bool owner = tid < 16 * UW;
+    const int bi = tid / UW, ju = tid % UW;
+    const int b = b0 + bi, j = j0 + ju;
+    const bool valid = owner && b < B && j < H;
+    const int len = valid ? lengths[b] : 0;
+    float dcarry = 0.f;
+    const int64_t slotf = (int64_t)NJT * 16 * Hp;                       // floats per parity slot
+    float *xg = xP + ((int64_t)(d * NBT + bt) * 2) * slotf;
+    __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(xg, 0, (int)(2 * slotf * 4), 0x00020000);
+    unsigned *fl = flags + (d * NBT + bt) * NJT;
+    if (tid == 0) s_abort = 0;
+    __syncthreads();
+
+    for (int s = 0; s < T; ++s) {
+        const int t = d == 0 ? T - 1 - s : s;
+        const int tp = d == 0 ? t - 1 : t + 1;   // the forward pass's previous time
+        const int64_t grow = (((int64_t)t * B + b) * 2 + d) * 4 * H;
+        float ig = 0.f, fg = 0.f, gg = 0.f, og = 0.f, cc = 0.f, cp = 0.f, dh = 0.f;
+        const bool act = valid && t < len;
+        if (act) {
+            ig = G[grow + j]; fg = G[grow + H + j]; gg = G[grow + 2 * H + j]; og = G[grow + 3 * H + j];
+            cc = Cs[(((int64_t)t * B + b) * 2 + d) * H + j];
+            if (tp >= 0 && tp < T) cp = Cs[(((int64_t)tp * B + b) * 2 + d) * H + j];
+            dh = dHout[t * dho_t + b * dho_b + d * H + j];
+        }
+        if (s > 0) {
+            if (!tagmode) {
+                if (wave == 0 && !(dbg & 1)) {
+                    if (!poll_flags(fl, NJT, (unsigned)s)) {
+                        if (lane == 0) {
+                            s_abort = 1;
+                            __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        }
+                    }
+                }
+                __syncthreads();
+                if (s_abort) break;
+            }
+            {   // sum the NJT partial products of the previous step: every thread issues its
+                // share of the 16-byte loads at once (one memory round trip), then a fixed-order
+                // reduction through LDS
+                const int item = tid % NI, grp = tid / NI;
+                const int ib = item / (UW / 4), ih = item % (UW / 4);
+                const int jj = j0 + 4 * ih;                  // first unit of this item
+                const int off0 = (int)((((s - 1) & 1) * slotf + ((int64_t)(jj >> 4) * 16 + ib) * 16 + (jj & 15)) * 4);
+                float4 sum = zero4();
+                {
+                    constexpr int CH = 8;
+                    const unsigned want = (unsigned)(((s - 1) >> 1) & 1);
+                    for (int w0 = grp; w0 < NJT; w0 += NG * CH) {
+                        float4 v[CH];
+                        for (int spins = 0;; ++spins) {
+                            bool ok = true;
+#pragma unroll
+                            for (int c = 0; c < CH; ++c) {
+                                const int w = w0 + c * NG;
+                                const bool in = w < NJT;
+                                v[c] = ld4_sc1(rsrc, in ? off0 + (int)((int64_t)w * MTILES * 256 * 4) : OOB_OFF);
+                                ok = ok & (tags_ok(v[c], want) | !in);
+                            }
+                            if (!tagmode || (dbg & 1) || __all(ok)) break;   // wave-uniform
+                            if (spins >= SPIN_LIMIT) {
+                                if (lane == 0) {
+                                    s_abort = 1;
+                                    __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                }
+                                break;
+                            }
+                            __builtin_amdgcn_s_sleep(1);
+                        }
+#pragma unroll
+                        for (int c = 0; c < CH; ++c) {
+                            sum.x += v[c].x; sum.y += v[c].y; sum.z += v[c].z; sum.w += v[c].w;
+                        }
+                    }
+                }
+                *reinterpret_cast<float4 *>(&part[grp][item][0]) = sum;
+            }
+            __syncthreads();
+            if (s_abort) break;
+            if (act) {
+                const int item = bi * (UW / 4) + (ju >> 2);
+                float sum = 0.f;
+#pragma unroll
+                for (int gq = 0; gq < NG; ++gq) sum += part[gq][item][ju & 3];
+                dh += sum;
+            }
+        }
+        float d0 = 0.f, d1 = 0.f, d2 = 0.f, d3 = 0.f;
+        if (act) {
+            const float tc = tanh_f(cc);
+            const float dc = dcarry + dh * og * (1.f - tc * tc);
+            d0 = dc * gg * ig * (1.f - ig);
+            d1 = dc * cp * fg * (1.f - fg);
+            d2 = dc * ig * (1.f - gg * gg);
+            d3 = dh * tc * og * (1.f - og);
+            dcarry = dc * fg;
+        }
+        if (valid) {
+            G[grow + j] = d0; G[grow + H + j] = d1; G[grow + 2 * H + j] = d2; G[grow + 3 * H + j] = d3;
+        }
+        if (owner) {
+            dgl[bi][ju] = d0; dgl[bi][UW + ju] = d1; dgl[bi][2 * UW + ju] = d2; dgl[bi][3 * UW + ju] = d3;
+        }
+        __syncthreads();
+        if (s + 1 < T) {   // uniform
+            f32x4 acc[NMT];
+#pragma unroll
+            for (int mtl = 0; mtl < NMT; ++mtl) acc[mtl] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const float bv = dgl[i][4 * ks + q];
+#pragma unroll
+                for (int mtl = 0; mtl < NMT; ++mtl)
+                    acc[mtl] = __builtin_amdgcn_mfma_f32_16x16x4f32(areg[mtl][ks], bv, acc[mtl], 0, 0, 0);
+            }
+            if (!(dbg & 8)) {
+#pragma unroll
+                for (int mtl = 0; mtl < NMT; ++mtl) {
+                    const int mt = wave + 4 * mtl;
+                    if (mt < MTILES) {
+                        u32x4 pk = {__float_as_uint(acc[mtl][0]), __float_as_uint(acc[mtl][1]),
+                                    __float_as_uint(acc[mtl][2]), __float_as_uint(acc[mtl][3])};
+                        if (tagmode) {
+                            const unsigned e = (unsigned)((s >> 1) & 1);
+                            pk = u32x4{tag_bits(acc[mtl][0], e), tag_bits(acc[mtl][1], e), tag_bits(acc[mtl][2], e),
+                                       tag_bits(acc[mtl][3], e)};
+                        }
+                        const int64_t off = (s & 1) * slotf + (((int64_t)jt * MTILES + mt) * 16 + i) * 16 + 4 * q;
+                        __builtin_amdgcn_raw_buffer_store_b128(pk, rsrc, (int)(off * 4), 0, 16);
+                    }
+                }
+            }
+        }
+        if (!tagmode) {
+            if (!(dbg & 2)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (tid == 0)
+                __hip_atomic_store(fl + jt, (unsigned)(s + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
     }
 }
 
@@ -445,8 +662,26 @@ __global__ __launch_bounds__(256) void blstm_bwd_persist_kernel(
 #define BLSTM_ERR_WORD 1024     // sticky: set by a kernel whose poll timed out
 #define BLSTM_HX_OFF 2048
 
+static int bwd_unit_width(int B, int H) {   // 8 units per workgroup while the grid still fits one per CU
+    return (cdiv(H, 8) * 2 * cdiv(B, 16) <= 256 && cdiv(H, 8) <= 128) ? 8 : 16;
+}
+
 extern "C" int64_t asr_blstm_ws_floats(int B, int H) {
-    return BLSTM_HX_OFF + (int64_t)4 * cdiv(H, 4) * cdiv(B, 16) * 64 + 64;
+    const int64_t fwd = (int64_t)4 * cdiv(H, 4) * cdiv(B, 16) * 64;
+    const int uw = bwd_unit_width(B, H);
+    const int64_t bwd = (int64_t)2 * cdiv(B, 16) * 2 * cdiv(H, uw) * 16 * (cdiv(H, 16) * 16);
+    return BLSTM_HX_OFF + (fwd > bwd ? fwd : bwd) + 64;
+}
+
+// timing experiments only (tools/lstm_bench.py): bit 0 skips the in-launch waits, bit 1 the
+// store drain -- results are then WRONG; never set by the product path.
+static int g_dbg = 0;
+static int g_bwd_form = 0;   // bit 8 of the debug flags selects the older dG-exchange kernel (A/B timing)
+static int g_tagmode = 1;    // bit 9 selects the flag protocol instead of the in-band epoch tags
+extern "C" void asr_debug_set(int flags) {
+    g_dbg = flags & 0xff;
+    g_bwd_form = (flags >> 8) & 1;
+    g_tagmode = ((flags >> 9) & 1) ? 0 : 1;
 }
 
 static bool al16p(const void *p) { return (((uintptr_t)p) & 15) == 0; }
@@ -458,7 +693,7 @@ static bool launch_fwd_persist(int kq4, dim3 grid, hipStream_t st, const float *
 #define FWD_CASE(K)                                                                                       \
     case K:                                                                                               \
         hipLaunchKernelGGL((blstm_fwd_persist_kernel<MT, K>), grid, dim3(256), 0, st, W_hh, G, Cs, Hout,  \
-                           ho_t, ho_b, lengths, T, B, H, hx, flags, err);                                 \
+                           ho_t, ho_b, lengths, T, B, H, hx, flags, err, g_dbg, g_tagmode);               \
         return true;
     switch (kq4) {
         FWD_CASE(1) FWD_CASE(2) FWD_CASE(3) FWD_CASE(4) FWD_CASE(5) FWD_CASE(6) FWD_CASE(7) FWD_CASE(8)
@@ -482,6 +717,8 @@ extern "C" int asr_blstm_fwd(const float *W_hh, float *G, float *Cs, float *Hout
     unsigned *err = flags + BLSTM_ERR_WORD;
     float *hx = ws + BLSTM_HX_OFF;
     ASR_CHECK_HIP(hipMemsetAsync(flags, 0, sizeof(unsigned) * BLSTM_FLAG_WORDS, st));
+    if (g_tagmode)   // every exchanged float starts with the "wrong" epoch tag (LSB = 1)
+        ASR_CHECK_HIP(hipMemsetAsync(hx, 0xFF, sizeof(float) * (size_t)4 * NJ * MT * 64, st));
     dim3 grid(NJ, 2);
     bool ok = MT == 1 ? launch_fwd_persist<1>(kq4, grid, st, W_hh, G, Cs, Hout, ho_t, ho_b, lengths, T, B, H, hx,
                                               flags, err)
@@ -492,9 +729,9 @@ extern "C" int asr_blstm_fwd(const float *W_hh, float *G, float *Cs, float *Hout
     return ASR_OK;
 }
 
-extern "C" int asr_blstm_bwd(const float *W_hhT, float *G, const float *Cs, const float *dHout,
-                             int64_t dho_t, int64_t dho_b, const int32_t *lengths, float *dc_ws, int T,
-                             int B, int H, float *ws, void *stream) {
+extern "C" int asr_blstm_bwd(const float *W_hh, const float *W_hhT, float *G, const float *Cs,
+                             const float *dHout, int64_t dho_t, int64_t dho_b, const int32_t *lengths,
+                             float *dc_ws, int T, int B, int H, float *ws, void *stream) {
     ASR_CHECK_ARG(W_hhT && G && Cs && dHout && lengths && dc_ws, "blstm_bwd: null pointer");
     ASR_CHECK_ARG(T > 0 && B > 0 && H > 0, "blstm_bwd: bad shape T=%d B=%d H=%d", T, B, H);
     hipStream_t st = (hipStream_t)stream;
@@ -505,13 +742,55 @@ extern "C" int asr_blstm_bwd(const float *W_hhT, float *G, const float *Cs, cons
                    gbytes < (int64_t)0x7fffffff && al16p(W_hhT) && al16p(G) && al16p(ws);
     unsigned *flags = reinterpret_cast<unsigned *>(ws);
     unsigned *err = flags ? flags + BLSTM_ERR_WORD : nullptr;
+    // preferred: reduce-scatter form (needs the untransposed W_hh)
+    if (persist && W_hh != nullptr && g_bwd_form == 0) {
+        const int uw = bwd_unit_width(B, H);
+        const int njt = cdiv(H, uw), nmt = cdiv(cdiv(H, 16), 4);
+        const int64_t xbytes = (int64_t)2 * njt * 16 * (cdiv(H, 16) * 16) * 4;
+        if (njt <= 128 && njt * 2 * NBT <= 256 && 2 * NBT * njt <= BLSTM_FLAG_WORDS && xbytes < 0x7fffffff) {
+            dim3 g2(njt, 2, NBT);
+            float *xP = ws + BLSTM_HX_OFF;
+            bool launched = true;
+            ASR_CHECK_HIP(hipMemsetAsync(flags, 0, sizeof(unsigned) * BLSTM_FLAG_WORDS, st));
+            if (g_tagmode)
+                ASR_CHECK_HIP(hipMemsetAsync(xP, 0xFF, (size_t)xbytes * 2 * NBT, st));
+#define RS_CASE(U, N)                                                                                   \
+    hipLaunchKernelGGL((blstm_bwd_rs_kernel<U, N>), g2, dim3(256), 0, st, W_hh, G, Cs, dHout, dho_t,   \
+                       dho_b, lengths, T, B, H, xP, flags, err, g_dbg, g_tagmode)
+            if (uw == 8) {
+                switch (nmt) {
+                    case 1: RS_CASE(8, 1); break;
+                    case 2: RS_CASE(8, 2); break;
+                    case 3: RS_CASE(8, 3); break;
+                    case 4: RS_CASE(8, 4); break;
+                    case 5: RS_CASE(8, 5); break;
+                    case 6: RS_CASE(8, 6); break;
+                    default: launched = false;
+                }
+            } else {
+                switch (nmt) {
+                    case 4: RS_CASE(16, 4); break;
+                    case 5: RS_CASE(16, 5); break;
+                    case 6: RS_CASE(16, 6); break;
+                    case 7: RS_CASE(16, 7); break;
+                    case 8: RS_CASE(16, 8); break;
+                    default: launched = false;
+                }
+            }
+#undef RS_CASE
+            if (launched) {
+                ASR_CHECK_LAUNCH("blstm_bwd_rs_kernel");
+                return ASR_OK;
+            }
+        }
+    }
     dim3 grid(NJT, 2, NBT);
     if (persist) {
         ASR_CHECK_HIP(hipMemsetAsync(flags, 0, sizeof(unsigned) * BLSTM_FLAG_WORDS, st));
 #define BWD_CASE(K)                                                                                        \
     case K:                                                                                                \
         hipLaunchKernelGGL((blstm_bwd_persist_kernel<K>), grid, dim3(256), 0, st, W_hhT, G, Cs, dHout,     \
-                           dho_t, dho_b, lengths, T, B, H, flags, err);                                    \
+                           dho_t, dho_b, lengths, T, B, H, flags, err, g_dbg);                             \
         break;
         switch (kq4) {
             BWD_CASE(1) BWD_CASE(2) BWD_CASE(3) BWD_CASE(4) BWD_CASE(5) BWD_CASE(6) BWD_CASE(8) BWD_CASE(10)

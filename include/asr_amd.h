@@ -34,6 +34,9 @@ extern "C" {
 #define ASR_ERR_WORKSPACE (-3)
 
 int asr_version(void);
+/* timing experiments only: non-zero flags make the persistent kernels skip their
+ * in-launch waits (results are then wrong).  The product path never calls it. */
+void asr_debug_set(int flags);
 const char *asr_last_error(void);
 
 /* ------------------------------------------------------------------ loss --
@@ -132,13 +135,14 @@ int asr_blstm_fwd(const float *W_hh, float *G, float *Cs, float *Hout,
                   int T, int B, int H, float *ws, void *stream);
 
 /* Backward of the recurrence.
+ *   W_hh  [2][4H][H]   as in the forward (used by the persistent kernel; may be NULL)
  *   W_hhT [2][H][4H]   transposed recurrent weights (asr_transpose)
  *   G     in: activated gates; out: d loss / d pre-activation gates (0 at padding)
  *   dHout upstream gradient, element (t,b,dir*H+j) at t*dho_t + b*dho_b + dir*H + j
  *   dc_ws [2][B][H] scratch
  * The weight/input gradients are plain GEMMs over G afterwards (asr_sgemm).
  */
-int asr_blstm_bwd(const float *W_hhT, float *G, const float *Cs, const float *dHout,
+int asr_blstm_bwd(const float *W_hh, const float *W_hhT, float *G, const float *Cs, const float *dHout,
                   int64_t dho_t, int64_t dho_b, const int32_t *lengths,
                   float *dc_ws, int T, int B, int H, float *ws, void *stream);
 

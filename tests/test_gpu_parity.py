@@ -183,7 +183,9 @@ def test_persistent_and_stepwise_recurrence_agree():
         finally:
             E.PERSISTENT = True
     (h1, dx1, g1), (h2, dx2, g2) = outs
-    assert rel_err(h1, h2) < 1e-6
+    # the persistent kernels carry a 1-bit epoch tag in the mantissa LSB of the exchanged
+    # copies of h / the partial products: agreement is to a few ulp, not bitwise
+    assert rel_err(h1, h2) < 5e-6
     assert rel_err(dx1, dx2) < 1e-5
     for a, b_ in zip(g1, g2):
         assert rel_err(a, b_) < 1e-5
