@@ -26,9 +26,9 @@
 #define KW 100     // conv taps
 #define PADW 50    // conv padding
 #define TT 64      // frames per energy workgroup (= lanes)
-#define EW 8       // waves per energy workgroup
+#define EW 16      // waves per energy workgroup (4 per SIMD: the tanh chains are latency-bound)
 #define ACH (EW * 16)   // attention-dim chunk staged per pass
-#define TSTR (ACH + 1)  // LDS row stride of the staged tile (odd: conflict-free column reads)
+#define TILE_FLOATS (EW * TT * 17)   // eight per-wave tiles of 64 x 17 floats
 
 // ------------------------------------------------------------------ sproj --
 __global__ __launch_bounds__(256) void sproj_kernel(const float *__restrict__ S_s,
@@ -41,7 +41,7 @@ __global__ __launch_bounds__(256) void sproj_kernel(const float *__restrict__ S_
     const float *wrow = (n0 + i) < A ? W_se + (int64_t)(n0 + i) * Hd : nullptr;
     Tile16Acc acc;
     tile16_init(acc);
-    tile16_seg(acc, xrow, wrow, Hd, vec != 0);
+    tile16_seg(acc, xrow, wrow, Hd, vec != 0, W_se);
     tile16_reduce(acc, red);
     const int bi = threadIdx.x >> 4, ni = threadIdx.x & 15;
     if (b0 + bi < B && n0 + ni < A) sp[(int64_t)(b0 + bi) * A + n0 + ni] = tile16_get(red, bi, ni);
@@ -62,51 +62,52 @@ __device__ __forceinline__ void fill_uni(float *uni, const float *__restrict__ s
     }
 }
 
-// Stage PH[b][t0 .. t0+63][ac .. ac+ACH) into tile[64][TSTR]; rows >= nrows and
-// columns >= A are zero.  Split in two so the global loads of chunk c+1 are in
-// flight while chunk c is being consumed: stage_load (whole 512-byte row
-// segments, 16 B per lane) -> registers, stage_write registers -> LDS with the
-// four scalar writes of a float4 rotated so each write instruction hits distinct
-// banks.
-#define STAGE_N ((TT * ACH / 4) / (EW * 64))
-__device__ __forceinline__ void stage_load(float4 (&regs)[STAGE_N], const float *__restrict__ PHb, int t0,
-                                           int nrows, int ac, int A, bool vec) {
-    const int tid = threadIdx.x;
+// Per-wave staging of PH: wave w consumes columns [ac + 16w, ac + 16w + 16) of the
+// chunk for all 64 frames, so it stages exactly those 64 x 16 floats into its OWN LDS
+// tile (row stride 17: conflict-free column reads).  No workgroup barrier is needed
+// in the chunk loop -- the waves run decoupled and hide each other's latencies; LDS
+// operations of one wave execute in order.  The global loads of chunk c+1 are issued
+// before chunk c is consumed.  Loads are branch-free (masked), so all four are in
+// flight together.
+#define WCOLS 16
+#define WSTR 17
+__device__ __forceinline__ void wstage_load(float4 (&regs)[4], unsigned (&mask)[4],
+                                            const float *__restrict__ PHb, int t0, int nrows, int a0, int A,
+                                            bool vec) {
+    const int lane = threadIdx.x & 63;
 #pragma unroll
-    for (int it = 0; it < STAGE_N; ++it) {
-        const int f = tid + it * (EW * 64);
-        const int row = f / (ACH / 4), c4 = f % (ACH / 4);
-        const int a = ac + c4 * 4;
-        float4 v = zero4();
-        if (row < nrows && a < A) {
-            const float *src = PHb + (int64_t)(t0 + row) * A + a;
-            if (vec && a + 3 < A) {
-                v = ld4(src);
-            } else {
+    for (int it = 0; it < 4; ++it) {
+        const int f = lane + 64 * it;
+        const int row = f >> 2, a = a0 + (f & 3) * 4;
+        if (vec) {
+            const bool ok = row < nrows && a < A;      // A % 4 == 0: the whole float4 is in range
+            regs[it] = ld4(ok ? PHb + (int64_t)(t0 + row) * A + a : PHb);
+            mask[it] = ok ? 0xffffffffu : 0u;
+        } else {
+            float4 v = zero4();
+            if (row < nrows && a < A) {
+                const float *src = PHb + (int64_t)(t0 + row) * A + a;
                 v.x = src[0];
                 if (a + 1 < A) v.y = src[1];
                 if (a + 2 < A) v.z = src[2];
                 if (a + 3 < A) v.w = src[3];
             }
+            regs[it] = v;
+            mask[it] = 0xffffffffu;
         }
-        regs[it] = v;
     }
 }
-__device__ __forceinline__ void stage_write(float *tile, const float4 (&regs)[STAGE_N]) {
-    const int tid = threadIdx.x;
+__device__ __forceinline__ void wstage_write(float *wt, const float4 (&regs)[4], const unsigned (&mask)[4]) {
+    const int lane = threadIdx.x & 63;
 #pragma unroll
-    for (int it = 0; it < STAGE_N; ++it) {
-        const int f = tid + it * (EW * 64);
-        const int row = f / (ACH / 4), c4 = f % (ACH / 4);
-        const float v[4] = {regs[it].x, regs[it].y, regs[it].z, regs[it].w};
-        float *dst = tile + row * TSTR + c4 * 4;
-        const int rot = (c4 >> 3) & 3;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int e = (j + rot) & 3;
-            const float val = e == 0 ? v[0] : (e == 1 ? v[1] : (e == 2 ? v[2] : v[3]));
-            dst[e] = val;
-        }
+    for (int it = 0; it < 4; ++it) {
+        const int f = lane + 64 * it;
+        float *dst = wt + (f >> 2) * WSTR + (f & 3) * 4;
+        const unsigned m = mask[it];
+        dst[0] = __uint_as_float(__float_as_uint(regs[it].x) & m);
+        dst[1] = __uint_as_float(__float_as_uint(regs[it].y) & m);
+        dst[2] = __uint_as_float(__float_as_uint(regs[it].z) & m);
+        dst[3] = __uint_as_float(__float_as_uint(regs[it].w) & m);
     }
 }
 
@@ -132,7 +133,7 @@ __global__ __launch_bounds__(EW * 64) void energy_fwd_kernel(
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     float *uni = smem;
     float *tile = uni + round4(A * 12);
-    float *Fs = tile + round4(TT * TSTR);         // [TT][NCH]
+    float *Fs = tile + round4(TILE_FLOATS);         // [TT][NCH]
     float *aw = Fs + TT * NCH;                    // [TT + KW] alpha window
     float *cw = aw + round4(TT + KW);             // [NCH*KW]
     float *red = cw + NCH * KW;                   // [EW][64]
@@ -145,8 +146,10 @@ __global__ __launch_bounds__(EW * 64) void energy_fwd_kernel(
     }
     const int nrows = min(TT, len - t0);
     const float *PHb = PH + (int64_t)b * T * A;
-    float4 pf[STAGE_N];
-    stage_load(pf, PHb, t0, nrows, 0, A, vec != 0);   // in flight under the conv prologue
+    float4 pf[4];
+    unsigned pm[4];
+    float *wt = nullptr;
+    wstage_load(pf, pm, PHb, t0, nrows, wave * WCOLS, A, vec != 0);   // in flight under the conv prologue
 
     fill_uni(uni, sp ? sp + (int64_t)b * A : nullptr, w_ee, W_fe, A);
     if (alpha_prev) {
@@ -184,18 +187,19 @@ __global__ __launch_bounds__(EW * 64) void energy_fwd_kernel(
     }
 
     float eacc = 0.f;
+    wt = tile + wave * (TT * WSTR);
     for (int ac = 0; ac < A; ac += ACH) {
-        __syncthreads();
-        stage_write(tile, pf);
-        __syncthreads();
-        if (ac + ACH < A) stage_load(pf, PHb, t0, nrows, ac + ACH, A, vec != 0);
+        __builtin_amdgcn_wave_barrier();
+        wstage_write(wt, pf, pm);
+        __builtin_amdgcn_wave_barrier();
+        if (ac + ACH < A) wstage_load(pf, pm, PHb, t0, nrows, ac + ACH + wave * WCOLS, A, vec != 0);
         const int abase = ac + wave * 16;
-#pragma unroll 4
+#pragma unroll 8
         for (int aa = 0; aa < 16; ++aa) {
             const int a = abase + aa;
             if (a < A) {  // wave-uniform
                 const float *u = uni + a * 12;
-                float x = tile[lane * TSTR + wave * 16 + aa] + u[0];
+                float x = wt[lane * WSTR + aa] + u[0];
 #pragma unroll
                 for (int c = 0; c < NCH; ++c) x += F[c] * u[2 + c];
                 eacc += u[1] * tanh_f(x);
@@ -213,7 +217,7 @@ __global__ __launch_bounds__(EW * 64) void energy_fwd_kernel(
 }
 
 static size_t energy_fwd_smem(int A) {
-    return sizeof(float) * (size_t)(((A * 12 + 3) & ~3) + ((TT * TSTR + 3) & ~3) + TT * NCH +
+    return sizeof(float) * (size_t)(((A * 12 + 3) & ~3) + ((TILE_FLOATS + 3) & ~3) + TT * NCH +
                                     ((TT + KW + 3) & ~3) + NCH * KW + EW * 64);
 }
 
@@ -309,9 +313,9 @@ __global__ __launch_bounds__(256) void cell_fwd_kernel(
         Tile16Acc acc;
         tile16_init(acc);
         tile16_seg(acc, b < B ? S_s + (int64_t)b * Hd : nullptr, j < Hd ? W_ss + wr * Hd : nullptr, Hd,
-                   vec_s != 0);
+                   vec_s != 0, W_ss);
         tile16_seg(acc, b < B ? g_s + (int64_t)b * E : nullptr, j < Hd ? W_gs + wr * E : nullptr, E,
-                   vec_g != 0);
+                   vec_g != 0, W_gs);
         tile16_reduce(acc, red);
     }
     const int tid = threadIdx.x;
@@ -502,14 +506,14 @@ __global__ __launch_bounds__(1024) void dscell_kernel(
         Tile16Acc acc;
         tile16_init(acc);
         tile16_seg(acc, bv ? drec_n + (int64_t)b * 4 * Hd : nullptr, jv ? W_ssT + (int64_t)j * 4 * Hd : nullptr,
-                   4 * Hd, vec != 0);
+                   4 * Hd, vec != 0, W_ssT);
         tile16_seg(acc, bv ? dyp_n + (int64_t)b * Hd : nullptr, jv ? W_syT + (int64_t)j * Hd : nullptr, Hd,
-                   vec != 0);
+                   vec != 0, W_syT);
         int nparts = 1;
         if (bv) nparts = max(1, (min(lengths[b], T) + TT - 1) / TT);
         tile16_seg(acc, bv ? dsp_part + (int64_t)b * A : nullptr, jv ? W_seT + (int64_t)j * A : nullptr, A,
-                   vec != 0, nparts, part_stride,
-                   (blockIdx.x == 0 && bv) ? dsp_n + (int64_t)b * A : nullptr);
+                   vec != 0, W_seT, true, nparts, part_stride,
+                   (blockIdx.x == 0 && bv) ? dsp_n + (int64_t)b * A : nullptr, (T + TT - 1) / TT);
         tile16_reduce(acc, red);
     }
     const int tid = threadIdx.x;
@@ -547,9 +551,9 @@ __global__ __launch_bounds__(1024) void dg_kernel(const float *__restrict__ drec
     Tile16Acc acc;
     tile16_init(acc);
     tile16_seg(acc, b < B ? drec_s + (int64_t)b * 4 * Hd : nullptr, e < E ? W_gsT + (int64_t)e * 4 * Hd : nullptr,
-               4 * Hd, vec != 0);
+               4 * Hd, vec != 0, W_gsT);
     tile16_seg(acc, b < B ? dyp_s + (int64_t)b * Hd : nullptr, e < E ? W_gyT + (int64_t)e * Hd : nullptr, Hd,
-               vec != 0);
+               vec != 0, W_gyT);
     tile16_reduce(acc, red);
     const int tid = threadIdx.x;
     if (tid < 256) {
@@ -634,11 +638,13 @@ __global__ __launch_bounds__(EW * 64) void energy_bwd_kernel(
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     float *uni = smem;
     float *tile = uni + round4(A * 12);
-    float *red = tile + round4(TT * TSTR);   // [EW][64][NCH] (also used for the dot reduction)
+    float *red = tile + round4(TILE_FLOATS);   // [EW][64][NCH] (also used for the dot reduction)
     const int tid = threadIdx.x;
     const float *PHb = PH + (int64_t)b * T * A;
-    float4 pf[STAGE_N];
-    stage_load(pf, PHb, t0, nrows, 0, A, vec != 0);   // in flight under the prologue
+    float4 pf[4];
+    unsigned pm[4];
+    wstage_load(pf, pm, PHb, t0, nrows, wave * WCOLS, A, vec != 0);   // in flight under the prologue
+    float *wt = tile + wave * (TT * WSTR);
 
     // <alpha, dalpha> over the valid frames of this utterance
     float part = 0.f;
@@ -669,17 +675,17 @@ __global__ __launch_bounds__(EW * 64) void energy_bwd_kernel(
 
     float *dsp_out = dsp_part + ((int64_t)blockIdx.x * B + b) * A;
     for (int ac = 0; ac < A; ac += ACH) {
-        __syncthreads();
-        stage_write(tile, pf);
-        __syncthreads();
-        if (ac + ACH < A) stage_load(pf, PHb, t0, nrows, ac + ACH, A, vec != 0);
+        __builtin_amdgcn_wave_barrier();
+        wstage_write(wt, pf, pm);
+        __builtin_amdgcn_wave_barrier();
+        if (ac + ACH < A) wstage_load(pf, pm, PHb, t0, nrows, ac + ACH + wave * WCOLS, A, vec != 0);
         const int abase = ac + wave * 16;
-#pragma unroll 2
+#pragma unroll 4
         for (int aa = 0; aa < 16; ++aa) {
             const int a = abase + aa;
             if (a < A) {  // wave-uniform
                 const float *u = uni + a * 12;
-                float x = tile[lane * TSTR + wave * 16 + aa] + u[0];
+                float x = wt[lane * WSTR + aa] + u[0];
 #pragma unroll
                 for (int c = 0; c < NCH; ++c) x += F[c] * u[2 + c];
                 const float th = tanh_f(x);
@@ -705,7 +711,7 @@ __global__ __launch_bounds__(EW * 64) void energy_bwd_kernel(
 }
 
 static size_t energy_bwd_smem(int A) {
-    return sizeof(float) * (size_t)(((A * 12 + 3) & ~3) + ((TT * TSTR + 3) & ~3) + EW * 64 * NCH);
+    return sizeof(float) * (size_t)(((A * 12 + 3) & ~3) + ((TILE_FLOATS + 3) & ~3) + EW * 64 * NCH);
 }
 
 // ------------------------------------------------- after the loop: dPH etc --
@@ -859,8 +865,9 @@ extern "C" int64_t asr_attdec_bwd_ws_floats(int B, int T, int E, int Hd, int L) 
     n += (int64_t)B * T + 64;                    // dalpha
     n += (int64_t)B * Hd + 64;                   // dC carry
     n += nt * B * A + 64;                        // dsp partials
-    int64_t post = nt * B * A * 11 + A * 11 + 64;               // phase-2 partials + sums
-    int64_t conv = (int64_t)(L > 1 ? L - 1 : 1) * B * NCH * KW + 64;   // conv partials
+    int64_t post = nt * B * A * 11 + A * 11 + 64 + asr_colsum_ws_floats((int)(nt * B), (int)(A * 11)) + 64;
+    int64_t conv = (int64_t)(L > 1 ? L - 1 : 1) * B * NCH * KW + 64 +
+                   asr_colsum_ws_floats((L > 1 ? L - 1 : 1) * B, NCH * KW) + 64;
     n += post > conv ? post : conv;
     return n;
 }
@@ -939,8 +946,9 @@ extern "C" int asr_attdec_bwd(const asr_attdec_bwd_args *a, void *stream) {
         hipLaunchKernelGGL(phase2_kernel, dim3(nt, B, cdiv(A, P2_A)), dim3(256), 0, st, f->PH,
                            (const float *)f->sproj, (const float *)a->de, (const float *)f->Fc, f->w_ee,
                            f->W_fe, f->lengths, a->dPH, part, L, B, T, A);
-        hipLaunchKernelGGL(reduce_parts_kernel, dim3(cdiv((int64_t)A * 11, 256)), dim3(256), 0, st,
-                           (const float *)part, (int)(nt * B), (int64_t)A * 11, sum11);
+        // deterministic two-stage column sum over the (tile, b) partials
+        ASR_CHECK(asr_colsum(part, (int)(nt * B), A * 11, (int64_t)A * 11, 0, 0, sum11, 0,
+                             sum11 + A * 11 + 64, stream));
         hipLaunchKernelGGL(split_fe_kernel, dim3(cdiv((int64_t)A * 11, 256)), dim3(256), 0, st,
                            (const float *)sum11, A, a->dw_ee, a->dW_fe);
     }
@@ -949,8 +957,8 @@ extern "C" int asr_attdec_bwd(const asr_attdec_bwd_args *a, void *stream) {
         float *part = post;
         hipLaunchKernelGGL(dconv_kernel, dim3((L - 1) * B), dim3(128), csm, st, (const float *)a->dF,
                            (const float *)f->alpha, f->lengths, part, B, T);
-        hipLaunchKernelGGL(reduce_parts_kernel, dim3(cdiv(NCH * KW, 256)), dim3(256), 0, st,
-                           (const float *)part, (L - 1) * B, (int64_t)NCH * KW, a->dconv_w);
+        ASR_CHECK(asr_colsum(part, (L - 1) * B, NCH * KW, (int64_t)NCH * KW, 0, 0, a->dconv_w, 0,
+                             part + (int64_t)(L - 1) * B * NCH * KW + 64, stream));
     } else {
         ASR_CHECK_HIP(hipMemsetAsync(a->dconv_w, 0, sizeof(float) * NCH * KW, st));
     }

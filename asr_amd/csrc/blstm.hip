@@ -37,7 +37,7 @@ __global__ __launch_bounds__(256) void blstm_fwd_step_kernel(
         const float *wrow = j < H ? W_hh + ((int64_t)d * 4 * H + gate * H + j) * H : nullptr;
         Tile16Acc acc;
         tile16_init(acc);
-        tile16_seg(acc, xrow, wrow, H, vec != 0);
+        tile16_seg(acc, xrow, wrow, H, vec != 0, W_hh);
         tile16_reduce(acc, red);
     }
     const int tid = threadIdx.x;
@@ -117,7 +117,7 @@ __global__ __launch_bounds__(1024) void blstm_bwd_step_kernel(
         const float *wrow = j < H ? W_hhT + ((int64_t)d * H + j) * 4 * H : nullptr;
         Tile16Acc acc;
         tile16_init(acc);
-        tile16_seg(acc, xrow, wrow, 4 * H, vec != 0);
+        tile16_seg(acc, xrow, wrow, 4 * H, vec != 0, W_hhT);
         tile16_reduce(acc, red);
     }
     const int tid = threadIdx.x;

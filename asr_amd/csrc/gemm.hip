@@ -305,7 +305,20 @@ extern "C" int asr_sgemm(const asr_gemm_desc *din, void *stream) {
         case 2: LAUNCH(BM_, BN_, GK_, 1, 0, F); break;    \
         default: LAUNCH(BM_, BN_, GK_, 1, 1, F); break;   \
     }
-    if (big) {
+    static int tile_cfg = -1;
+    if (tile_cfg < 0) {
+        const char *e = getenv("ASR_GEMM_TILE");
+        tile_cfg = e ? atoi(e) : 2;   // 128 x 64 measured best on the config-2 shapes (tools/gemm_bench.py)
+    }
+    if (big && fast && tile_cfg == 1) {          // experiment: 64 x 128 tiles
+        dim3 grid(cdiv(d.N, 128), cdiv(d.M, 64), d.nbatch * splitk);
+        ASR_CHECK_ARG(grid.y <= 65535 && grid.z <= 65535, "sgemm: grid too large");
+        LAUNCH_MODES(64, 128, 16, true)
+    } else if (big && fast && tile_cfg == 2) {   // default: 128 x 64 tiles (more, smaller tiles: shorter tail)
+        dim3 grid(cdiv(d.N, 64), cdiv(d.M, 128), d.nbatch * splitk);
+        ASR_CHECK_ARG(grid.y <= 65535 && grid.z <= 65535, "sgemm: grid too large");
+        LAUNCH_MODES(128, 64, 16, true)
+    } else if (big) {
         dim3 grid(cdiv(d.N, 128), cdiv(d.M, 128), d.nbatch * splitk);
         ASR_CHECK_ARG(grid.y <= 65535 && grid.z <= 65535, "sgemm: grid too large");
         if (fast && GK == 32) { LAUNCH_MODES(128, 128, 32, true) }

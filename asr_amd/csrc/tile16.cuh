@@ -28,6 +28,16 @@ __device__ __forceinline__ void tile16_init(Tile16Acc &acc) {
     for (int r = 0; r < 4; ++r) { acc.a0[r] = 0.f; acc.a1[r] = 0.f; }
 }
 
+// fast: K % 4 == 0 and 16-byte aligned rows -> unconditional masked load (no branch, so
+// all loads of an unrolled loop are in flight together); `safe` is any valid aligned address.
+__device__ __forceinline__ float4 t16_load_fast(const float *row, int k, int ke, const float *safe) {
+    const bool ok = row != nullptr && k < ke;
+    const float4 q = ld4(ok ? row + k : safe);
+    const unsigned m = ok ? 0xffffffffu : 0u;
+    return make_float4(__uint_as_float(__float_as_uint(q.x) & m), __uint_as_float(__float_as_uint(q.y) & m),
+                       __uint_as_float(__float_as_uint(q.z) & m), __uint_as_float(__float_as_uint(q.w) & m));
+}
+
 __device__ __forceinline__ float4 t16_load(const float *row, int k, int ke, bool vec) {
     float4 v = zero4();
     if (row != nullptr && k < ke) {
@@ -49,15 +59,52 @@ __device__ __forceinline__ float4 t16_load(const float *row, int k, int ke, bool
 // (partial sums left by an earlier kernel); if `sum_out` is non-null the summed
 // A values are also stored there (same indexing as xrow).
 // The trip count is uniform over the workgroup: every wave issues the same MFMAs.
+// safe: any mapped, 16-byte aligned address (masked lanes load from it); parts: UNIFORM
+// flag selecting the partial-sum form (nparts / sum_out may then differ per lane).
 __device__ __forceinline__ void tile16_seg(Tile16Acc &acc, const float *xrow, const float *wrow, int K,
-                                           bool vec, int nparts = 1, int64_t pstride = 0,
-                                           float *sum_out = nullptr) {
+                                           bool vec, const float *safe, bool parts = false, int nparts = 1,
+                                           int64_t pstride = 0, float *sum_out = nullptr, int nparts_max = 1) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
     const int slots = nw * 4;
     int kq = (K + slots - 1) / slots;
     kq = (kq + 3) & ~3;
     const int kb = (wave * 4 + (lane >> 4)) * kq;
     const int ke = min(K, kb + kq);
+    if (vec && (K & 3) == 0 && !parts) {   // uniform
+#pragma unroll 4
+        for (int u = 0; u < kq; u += 4) {
+            const int k = kb + u;
+            const float4 a = t16_load_fast(xrow, k, ke, safe);
+            const float4 b = t16_load_fast(wrow, k, ke, safe);
+            acc.a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b.x, acc.a0, 0, 0, 0);
+            acc.a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b.y, acc.a1, 0, 0, 0);
+            acc.a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b.z, acc.a0, 0, 0, 0);
+            acc.a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b.w, acc.a1, 0, 0, 0);
+        }
+        return;
+    }
+    if (vec && (K & 3) == 0 && parts) {   // uniform: branch-free partial-sum form, 8 parts in flight
+        for (int u = 0; u < kq; u += 4) {
+            const int k = kb + u;
+            float4 a = zero4();
+            for (int p0 = 0; p0 < nparts_max; p0 += 8) {   // uniform bound; lanes mask p >= nparts
+                float4 t[8];
+#pragma unroll
+                for (int c = 0; c < 8; ++c)
+                    t[c] = t16_load_fast((xrow != nullptr && p0 + c < nparts) ? xrow + (p0 + c) * pstride : nullptr,
+                                         k, ke, safe);
+#pragma unroll
+                for (int c = 0; c < 8; ++c) { a.x += t[c].x; a.y += t[c].y; a.z += t[c].z; a.w += t[c].w; }
+            }
+            if (sum_out != nullptr && xrow != nullptr && k < ke) *reinterpret_cast<float4 *>(sum_out + k) = a;
+            const float4 b = t16_load_fast(wrow, k, ke, safe);
+            acc.a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b.x, acc.a0, 0, 0, 0);
+            acc.a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b.y, acc.a1, 0, 0, 0);
+            acc.a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b.z, acc.a0, 0, 0, 0);
+            acc.a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b.w, acc.a1, 0, 0, 0);
+        }
+        return;
+    }
 #pragma unroll 2
     for (int u = 0; u < kq; u += 4) {
         const int k = kb + u;

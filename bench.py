@@ -62,10 +62,11 @@ def make_batch(hp, dev, seed=1234, B=32, t_hi=1500, t_lo=900, L=100, l_lo=50):
     return x.to(dev), lengths, tgt.to(dev), text_len.to(dev)
 
 
-def cpu_baseline(hp, seconds_hint=25.0):
-    """The CPU restatement of the reference (oracle/ref_model.py, stock PyTorch
-    ops in the reference's op order) timed on this host: fwd + loss + bwd on a
-    bounded sample of the same workload -- every 4th utterance of the batch (B=8)."""
+def cpu_baseline(hp):
+    """The CPU restatement of the reference (oracle/ref_model.py: stock PyTorch ops
+    in the reference's op order -- nn.LSTM over a packed batch, per-step Linear /
+    Conv1d attention, dense one-hot loss) timed on this host: ONE fwd + loss + bwd
+    step of the same config-2 batch (B=32), i.e. the same workload, 1 step."""
     from oracle import ref_model as R
     threads = min(os.cpu_count() or 1, int(os.environ.get("OMP_NUM_THREADS", "16")), 16)
     torch.set_num_threads(threads)
@@ -73,17 +74,15 @@ def cpu_baseline(hp, seconds_hint=25.0):
     m = R.AttModel(hp).train()
     cpu = torch.device("cpu")
     x, lengths, tgt, tl = make_batch(hp, cpu)
-    sel = torch.arange(0, x.shape[0], 4)
-    x, lengths, tgt, tl = x[sel].contiguous(), lengths[sel], tgt[sel].contiguous(), tl[sel]
-    frames = int((lengths * hp.frame_stacking).sum())   # mel frames (multiples of 3 here)
+    frames = make_batch.mel_frames
     t0 = time.time()
     y = m(x, lengths, tgt)
     loss = R.label_smoothing_loss(y, tgt, tl, hp.T_norm, hp.B_norm)
     loss.backward()
     dt = time.time() - t0
     return {"value": frames / dt, "unit": "frames/s", "cores": threads, "kind": "port",
-            "sample": f"1 step fwd+loss+bwd of every 4th utterance of the config-2 batch (B=8, {frames} mel "
-                      f"frames, L=100) in {dt:.1f} s with torch CPU ops on {threads} threads"}
+            "sample": f"1 step fwd+loss+bwd of the full config-2 batch (B=32, {frames} mel frames, L=100) "
+                      f"in {dt:.1f} s with torch CPU ops on {threads} threads"}
 
 
 def time_kernel_events(fn, iters):
@@ -101,31 +100,72 @@ def time_kernel_events(fn, iters):
 
 
 def roofline_probe(hp, dev):
-    """Times the dominant kernels of the step in isolation with HIP events (same
-    shapes as the timed step) and prices them against the gfx950 peaks."""
-    from asr_amd import ops
+    """Times the step's main kernels in isolation with HIP events on the launch
+    stream (same shapes as the timed step) and prices them against the gfx950 peaks
+    of MI355X_MICROARCH.md.  The first entry is the dominant kernel of the step."""
+    import ctypes as C
+    from asr_amd import _lib, ops
+    lib = _lib.load()
     H = hp.num_hidden_nodes_encoder
     B, T = 32, 500
     out = {}
-    # (1) input-projection GEMM of an upper encoder layer: (T*B x 2H) @ (2H x 4H), fp32 MFMA
-    M, N, K = T * B, 4 * H, 2 * H
     g = torch.Generator(device="cpu").manual_seed(1)
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    # (1) BLSTM recurrence, one layer = one launch: T steps x 2 dirs x (B x H) @ (H x 4H)
+    W = (torch.randn(2, 4 * H, H, generator=g) * 0.05).to(dev)
+    G0 = torch.randn(T, B, 2, 4 * H, generator=g).to(dev)
+    Gw = G0.clone()
+    Cs = torch.empty(T, B, 2, H, device=dev)
+    Hout = torch.empty(T, B, 2 * H, device=dev)
+    lengths = torch.linspace(500, 300, B).to(torch.int32).to(dev)
+    ws = torch.zeros(int(lib.asr_blstm_ws_floats(B, H)), device=dev)
+
+    def lstm_fwd():
+        lib.asr_blstm_fwd(W.data_ptr(), Gw.data_ptr(), Cs.data_ptr(), Hout.data_ptr(), B * 2 * H, 2 * H,
+                          lengths.data_ptr(), T, B, H, ws.data_ptr(), st)
+    dt = time_kernel_events(lstm_fwd, 5)
+    # all B rows run all T steps in the kernel (padded rows are masked, not skipped)
+    flops = T * 2 * (2.0 * B * H * 4 * H)
+    out["blstm_fwd"] = {"bound": "mfma", "achieved": flops / dt / 1e12, "peak": MFMA_F32_PEAK_TFLOPS,
+                        "unit": "TFLOP/s", "frac": flops / dt / 1e12 / MFMA_F32_PEAK_TFLOPS, "traffic": None,
+                        "kernel": "blstm_fwd_persist_kernel<2,5>", "shape": [T, B, H], "avg_us": dt * 1e6,
+                        "us_per_time_step": dt * 1e6 / T,
+                        "note": "latency-bound recurrence: 500 dependent steps per launch"}
+    # (2) input-projection GEMM of an upper encoder layer: (T*B x 2H) @ (2H x 4H), fp32 MFMA
+    M, N, K = T * B, 4 * H, 2 * H
     A = torch.randn(M, K, generator=g).to(dev)
-    W = torch.randn(N, K, generator=g).to(dev)
+    Wp = torch.randn(N, K, generator=g).to(dev)
     Cm = torch.empty(M, N, device=dev)
-    dt = time_kernel_events(lambda: ops.sgemm(A, W, Cm, M, N, K, a_stride=K, b_stride=K, c_stride=N), 20)
+    dt = time_kernel_events(lambda: ops.sgemm(A, Wp, Cm, M, N, K, a_stride=K, b_stride=K, c_stride=N), 20)
     flops = 2.0 * M * N * K
     out["sgemm_proj"] = {"bound": "mfma", "achieved": flops / dt / 1e12, "peak": MFMA_F32_PEAK_TFLOPS,
                          "unit": "TFLOP/s", "frac": flops / dt / 1e12 / MFMA_F32_PEAK_TFLOPS, "traffic": None,
-                         "kernel": "sgemm_kernel<128,128>", "shape": [M, N, K], "avg_us": dt * 1e6}
+                         "kernel": "sgemm_kernel<128,128,16,0,0,true>", "shape": [M, N, K], "avg_us": dt * 1e6}
+    # (3) fused label-smoothed CE: logits read once + gradient written once
+    Bq, L, V = 32, 100, hp.num_classes
+    z = torch.randn(Bq, L, V, generator=g).to(dev)
+    tg = torch.randint(0, V, (Bq, L), generator=g).to(dev)
+    tl = torch.full((Bq,), L, dtype=torch.int64, device=dev)
+    row = torch.empty(Bq * L, device=dev)
+    ls = torch.empty((), device=dev)
+    dz = torch.empty_like(z)
+
+    def loss_k():
+        lib.asr_ls_ce_fwd_bwd(z.data_ptr(), tg.data_ptr(), tl.data_ptr(), Bq, L, V, C.c_float(0.1), 1, 0,
+                              row.data_ptr(), ls.data_ptr(), dz.data_ptr(), st)
+    dt = time_kernel_events(loss_k, 50)
+    nbytes = 2.0 * Bq * L * V * 4
+    out["ls_ce"] = {"bound": "hbm", "achieved": nbytes / dt / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": nbytes / dt / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                    "kernel": "ls_ce_kernel<1> + ls_sum_kernel", "shape": [Bq, L, V], "avg_us": dt * 1e6}
     return out
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dropout", type=float, default=0.2, help="encoder dropout (template default 0.2)")
     args = ap.parse_args()
@@ -220,7 +260,7 @@ def main():
         }
         probes = roofline_probe(hp, dev) if world == 1 else {}
         if probes:
-            res["roofline"] = {k: v for k, v in probes["sgemm_proj"].items()}
+            res["roofline"] = dict(probes["blstm_fwd"])
             res["roofline_all"] = probes
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(make_hp(encoder_dropout=0.0))
