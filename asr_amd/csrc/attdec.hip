@@ -20,6 +20,8 @@
 // W_fe) are wave-uniform LDS broadcasts.  PH tiles are staged through LDS with
 // full-line global reads and read back transposed, bank-conflict free.
 // HBM/L3 traffic per step: PH once (energy) + hbatch once (ctx) = 2*B*T*A*4 B.
+#include <stdlib.h>
+
 #include "tile16.cuh"
 
 #define NCH 10     // conv channels  (Models/attention.py:22)
@@ -392,11 +394,322 @@ __global__ __launch_bounds__(1024) void greedy_out_kernel(
     }
 }
 
+
+// ======================================================================= v2 ==
+// Energy kernels on the matrix cores.  The conv-feature term of the energy,
+//     pre[t][a] = PH[t][a] + sproj[a] + sum_c F[t][c] W_fe[a][c],
+// is a (16 a) x (16 t) x (K = 12) product per tile: three v_mfma_f32_16x16x4_f32 with
+// the accumulator initialised to PH + sproj.  The C/D layout puts 4 consecutive a
+// of one frame on a lane (rows a = 4q + r, column t), so PH is read straight from
+// global memory as one 16-byte load per lane and tile (two adjacent tiles = one
+// 128-byte line per frame) -- no LDS staging, no transposition -- and the ten FMAs per
+// element of the scalar form disappear from the VALU.  In the backward the same
+// registers are the B operand of dF^T[c][t] += W_fe^T[c][a] dpre[a][t] (four MFMAs
+// per tile, accumulated over all tiles), so dF needs no cross-lane traffic either;
+// only dsproj[a] = sum_t dpre[t][a] is reduced across the 16 lanes of a row.
+// Workgroup = (b, 64 frames): 16 waves = 4 frame tiles x 4 slices of the attention
+// dimension.  Requires A % 4 == 0 and 16-byte aligned PH (else the scalar kernels).
+#define E2W 16
+#define E2P (E2W / 4)
+#define E2PF 4      // PH tiles loaded ahead per wave
+
+struct E2Smem {
+    float *sp, *wee, *wfe, *Fs, *aw, *cw, *red, *dspl, *dFl;
+};
+__device__ __forceinline__ int round16(int x) { return (x + 15) & ~15; }
+
+// Padded copies of W_fe ([A16][12], channels 10/11 and rows >= A zero) and w_ee ([A16]),
+// built once per forward/backward call so the per-step kernels fill their LDS tables with
+// straight 16-byte copies (all loads issued before the first store).
+__global__ __launch_bounds__(256) void e2_prep_kernel(const float *__restrict__ w_ee,
+                                                      const float *__restrict__ W_fe, int A, int A16,
+                                                      float *__restrict__ tab) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx < A16 * 12) {
+        const int a = idx / 12, c = idx - a * 12;
+        tab[idx] = (a < A && c < NCH) ? W_fe[a * NCH + c] : 0.f;
+    }
+    if (idx < A16) tab[A16 * 12 + idx] = idx < A ? w_ee[idx] : 0.f;
+}
+
+// tab = [wfe_pad (A16*12) | wee_pad (A16)] in global memory; m.wfe and m.wee are contiguous in LDS
+// in the same order.  sp_b: this utterance's sproj row or null.
+__device__ __forceinline__ void e2_tables(const E2Smem &m, const float *__restrict__ sp_b,
+                                          const float *__restrict__ tab, int A, int A16) {
+    const int tid = threadIdx.x, nt = blockDim.x;
+    const int n4 = A16 * 13 / 4;                       // A16 % 16 == 0
+    float4 r[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int f = tid + i * nt;
+        r[i] = ld4(tab + 4 * (f < n4 ? f : 0));
+    }
+    float4 s4 = zero4();
+    const int a4 = tid * 4;
+    if (sp_b != nullptr && a4 < A) s4 = ld4(sp_b + a4);  // A % 4 == 0 on this path
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int f = tid + i * nt;
+        if (f < n4) *reinterpret_cast<float4 *>(m.wfe + 4 * f) = r[i];
+    }
+    for (int f = tid + 4 * nt; f < n4; f += nt) *reinterpret_cast<float4 *>(m.wfe + 4 * f) = ld4(tab + 4 * f);
+    if (a4 < A16) *reinterpret_cast<float4 *>(m.sp + a4) = s4;
+    for (int a = a4 + 4 * nt; a < A16; a += 4 * nt)
+        *reinterpret_cast<float4 *>(m.sp + a) = (sp_b != nullptr && a < A) ? ld4(sp_b + a) : zero4();
+}
+
+__device__ __forceinline__ float4 e2_load_ph(const float *__restrict__ PHrow, bool rowok, int a4, int A,
+                                             const float *safe) {
+    const bool ok = rowok && a4 < A;
+    const float4 q = ld4(ok ? PHrow + a4 : safe);
+    const unsigned mk = ok ? 0xffffffffu : 0u;
+    return make_float4(__uint_as_float(__float_as_uint(q.x) & mk), __uint_as_float(__float_as_uint(q.y) & mk),
+                       __uint_as_float(__float_as_uint(q.z) & mk), __uint_as_float(__float_as_uint(q.w) & mk));
+}
+
+// pre-activation tile: acc[r] = pre[t][16*mt + 4q + r]
+__device__ __forceinline__ f32x4 e2_pre(const E2Smem &m, int mt, int q, int col, const float4 &ph,
+                                        const float (&fB)[3]) {
+    const float4 s4 = *reinterpret_cast<const float4 *>(m.sp + 16 * mt + 4 * q);
+    f32x4 acc = {ph.x + s4.x, ph.y + s4.y, ph.z + s4.z, ph.w + s4.w};
+    const float *wrow = m.wfe + (16 * mt + col) * 12 + q;
+#pragma unroll
+    for (int ks = 0; ks < 3; ++ks)
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wrow[4 * ks], fB[ks], acc, 0, 0, 0);
+    return acc;
+}
+
+__global__ __launch_bounds__(E2W * 64) void energy_fwd2_kernel(
+    const float *__restrict__ PH, const float *__restrict__ alpha_prev, const float *__restrict__ sp,
+    const float *__restrict__ tab, const float *__restrict__ conv_w,
+    const int32_t *__restrict__ lengths, float *__restrict__ e_buf, float *__restrict__ Fc_s, int T, int A,
+    int dbg) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int b = blockIdx.y, t0 = blockIdx.x * TT;
+    const int len = min(lengths[b], T);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int A16 = round16(A);
+    E2Smem m;
+    m.sp = smem;
+    m.wfe = m.sp + A16;
+    m.wee = m.wfe + A16 * 12;
+    m.Fs = m.wee + A16;               // [TT][12]
+    m.aw = m.Fs + TT * 12;            // [TT + KW]
+    m.cw = m.aw + round4(TT + KW);    // [NCH*KW]
+    m.red = m.cw + NCH * KW;          // [E2P][64]
+    float *Fout = Fc_s + ((int64_t)b * T + t0) * NCH;
+    if (t0 >= len) {
+        const int n = min(TT, T - t0) * NCH;
+        for (int i = tid; i < n; i += blockDim.x) Fout[i] = 0.f;
+        return;
+    }
+    const int nrows = min(TT, len - t0);
+    const int q = lane >> 4, col = lane & 15;
+    const int tt = wave & 3, part = wave >> 2;
+    const int tl = 16 * tt + col;
+    const bool rowok = tl < nrows && !(dbg & 1);
+    const float *PHrow = PH + ((int64_t)b * T + t0 + tl) * A;
+    const int MT = A16 / 16, MTP = (MT + E2P - 1) / E2P;
+    const int mt0 = part * MTP, mt1 = (dbg & 2) ? mt0 : min(MT, mt0 + MTP);
+    // the PH loads do not depend on the prologue: put them in flight first
+    float4 ph[E2PF];
+#pragma unroll
+    for (int jx = 0; jx < E2PF; ++jx)
+        ph[jx] = e2_load_ph(PHrow, rowok && mt0 + jx < mt1, 16 * (mt0 + jx) + 4 * q, A, PH);
+    e2_tables(m, sp ? sp + (int64_t)b * A : nullptr, tab, A, A16);
+    if (alpha_prev) {
+        for (int i = tid; i < TT + KW; i += blockDim.x) {
+            const int t = t0 - PADW + i;
+            m.aw[i] = (t >= 0 && t < T) ? alpha_prev[(int64_t)b * T + t] : 0.f;
+        }
+        for (int i = tid; i < NCH * KW; i += blockDim.x) m.cw[i] = conv_w[i];
+    }
+    __syncthreads();
+    // conv features F[t][c] = sum_k cw[c][k] alpha_prev[t + k - PADW] as a Toeplitz product on the
+    // matrix cores: waves 0..3 take 16 frames each, M = t, N = c (16, 10 used), K = 100 taps.
+    if (wave < 4) {
+        const int q = lane >> 4, col = lane & 15;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        if (alpha_prev) {
+            const float *arow = m.aw + 16 * wave + col + q;                       // A[t][k] = aw[t + k]
+            const float *brow = m.cw + (col < NCH ? col : 0) * KW + q;           // B[k][c] = cw[c][k]
+#pragma unroll 5
+            for (int ks = 0; ks < KW / 4; ++ks) {
+                const float bv = col < NCH ? brow[4 * ks] : 0.f;
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(arow[4 * ks], bv, acc, 0, 0, 0);
+            }
+        }
+        // D[t = 4q + r][c = col]
+        if (col < 12) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) m.Fs[(16 * wave + 4 * q + r) * 12 + col] = acc[r];
+        }
+    }
+    __syncthreads();
+    {
+        const int n = min(TT, T - t0) * NCH;
+        for (int i = tid; i < n; i += blockDim.x) Fout[i] = m.Fs[(i / NCH) * 12 + (i % NCH)];
+    }
+    float fB[3];
+#pragma unroll
+    for (int ks = 0; ks < 3; ++ks) fB[ks] = m.Fs[tl * 12 + 4 * ks + q];
+    float e = 0.f;
+    // all PH loads of a chunk of tiles are issued before the first one is consumed: the
+    // kernel is bound by memory latency, not by arithmetic
+    for (int mc = mt0; mc < mt1; mc += E2PF) {
+        if (mc != mt0) {
+#pragma unroll
+            for (int jx = 0; jx < E2PF; ++jx)
+                ph[jx] = e2_load_ph(PHrow, rowok && mc + jx < mt1, 16 * (mc + jx) + 4 * q, A, PH);
+        }
+#pragma unroll
+        for (int jx = 0; jx < E2PF; ++jx) {
+            const int mt = mc + jx;
+            if (mt < mt1) {   // uniform
+                const f32x4 acc = e2_pre(m, mt, q, col, ph[jx], fB);
+                const float4 w4 = *reinterpret_cast<const float4 *>(m.wee + 16 * mt + 4 * q);
+                e += w4.x * tanh_f(acc[0]) + w4.y * tanh_f(acc[1]) + w4.z * tanh_f(acc[2]) + w4.w * tanh_f(acc[3]);
+            }
+        }
+    }
+    e += __shfl_xor(e, 16, 64);
+    e += __shfl_xor(e, 32, 64);
+    if (q == 0) m.red[part * 64 + tl] = e;
+    __syncthreads();
+    if (tid < nrows) {
+        float v = 0.f;
+#pragma unroll
+        for (int p = 0; p < E2P; ++p) v += m.red[p * 64 + tid];
+        e_buf[(int64_t)b * T + t0 + tid] = v;
+    }
+}
+
+static size_t energy_fwd2_smem(int A) {
+    const int A16 = (A + 15) & ~15;
+    return sizeof(float) * (size_t)(A16 * 14 + TT * 12 + ((TT + KW + 3) & ~3) + NCH * KW + E2P * 64);
+}
+
+__global__ __launch_bounds__(E2W * 64) void energy_bwd2_kernel(
+    const float *__restrict__ PH, const float *__restrict__ alpha_s, const float *__restrict__ dalpha,
+    const float *__restrict__ sp, const float *__restrict__ tab,
+    const float *__restrict__ Fc_s, const int32_t *__restrict__ lengths, float *__restrict__ de_s,
+    float *__restrict__ dF_s, float *__restrict__ dsp_part, int B, int T, int A) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int b = blockIdx.y, t0 = blockIdx.x * TT;
+    const int len = min(lengths[b], T);
+    if (t0 >= len) return;
+    const int nrows = min(TT, len - t0);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int A16 = round16(A);
+    E2Smem m;
+    m.sp = smem;
+    m.wfe = m.sp + A16;
+    m.wee = m.wfe + A16 * 12;
+    m.Fs = m.wee + A16;                // [TT][12]
+    m.red = m.Fs + TT * 12;            // [E2W]
+    m.dspl = m.red + 64;               // [4][A16]
+    m.dFl = m.dspl + 4 * A16;          // [E2P][TT][16]
+    const int q = lane >> 4, col = lane & 15;
+    const int tt = wave & 3, prt = wave >> 2;
+    const int tl = 16 * tt + col;
+    const bool rowok = tl < nrows;
+    const float *PHrow = PH + ((int64_t)b * T + t0 + tl) * A;
+    const int MT = A16 / 16, MTP = (MT + E2P - 1) / E2P;
+    const int mt0 = prt * MTP, mt1 = min(MT, mt0 + MTP);
+    float4 ph[E2PF];                   // in flight under the prologue
+#pragma unroll
+    for (int jx = 0; jx < E2PF; ++jx)
+        ph[jx] = e2_load_ph(PHrow, rowok && mt0 + jx < mt1, 16 * (mt0 + jx) + 4 * q, A, PH);
+    float part = 0.f;
+    for (int t = tid; t < len; t += E2W * 64) part += alpha_s[(int64_t)b * T + t] * dalpha[(int64_t)b * T + t];
+    part = wave_sum(part);
+    if (lane == 0) m.red[wave] = part;
+    e2_tables(m, sp + (int64_t)b * A, tab, A, A16);
+    for (int i = tid; i < TT * 12; i += blockDim.x) {
+        const int r = i / 12, c = i - r * 12;
+        m.Fs[i] = (r < nrows && c < NCH) ? Fc_s[((int64_t)b * T + t0 + r) * NCH + c] : 0.f;
+    }
+    __syncthreads();
+    float dot = 0.f;
+#pragma unroll
+    for (int w = 0; w < E2W; ++w) dot += m.red[w];
+    float de = 0.f;
+    if (rowok) {
+        const int64_t ti = (int64_t)b * T + t0 + tl;
+        de = alpha_s[ti] * (dalpha[ti] - dot);
+        if (prt == 0 && q == 0) de_s[ti] = de;
+    }
+    float fB[3];
+#pragma unroll
+    for (int ks = 0; ks < 3; ++ks) fB[ks] = m.Fs[tl * 12 + 4 * ks + q];
+    f32x4 dFacc = {0.f, 0.f, 0.f, 0.f};     // dF^T[c = 4q + r][t = col], partial over this wave's a-range
+    for (int mc = mt0; mc < mt1; mc += E2PF) {
+        if (mc != mt0) {
+#pragma unroll
+            for (int jx = 0; jx < E2PF; ++jx)
+                ph[jx] = e2_load_ph(PHrow, rowok && mc + jx < mt1, 16 * (mc + jx) + 4 * q, A, PH);
+        }
+#pragma unroll
+        for (int jx = 0; jx < E2PF; ++jx) {
+            const int mt = mc + jx;
+            if (mt < mt1) {   // uniform
+                const f32x4 acc = e2_pre(m, mt, q, col, ph[jx], fB);
+                const float4 w4 = *reinterpret_cast<const float4 *>(m.wee + 16 * mt + 4 * q);
+                float dp[4];
+                {
+                    const float t0h = tanh_f(acc[0]), t1h = tanh_f(acc[1]), t2h = tanh_f(acc[2]), t3h = tanh_f(acc[3]);
+                    dp[0] = de * w4.x * (1.f - t0h * t0h);
+                    dp[1] = de * w4.y * (1.f - t1h * t1h);
+                    dp[2] = de * w4.z * (1.f - t2h * t2h);
+                    dp[3] = de * w4.w * (1.f - t3h * t3h);
+                }
+                // dF^T[c][t] += sum_a W_fe[a][c] dpre[t][a]: k-step r pairs a = 16mt + 4q + r on both operands
+                const float *wcol = m.wfe + (16 * mt + 4 * q) * 12 + col;   // col >= 12 reads the next row: masked below
+        #pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float av = col < 12 ? wcol[r * 12] : 0.f;
+                    dFacc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, dp[r], dFacc, 0, 0, 0);
+                }
+                // dsproj[a] partial: sum over the 16 frames of this tile (the 16 lanes with equal q)
+        #pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float v = dp[r];
+                    v += __shfl_xor(v, 8, 64);
+                    v += __shfl_xor(v, 4, 64);
+                    v += __shfl_xor(v, 2, 64);
+                    v += __shfl_xor(v, 1, 64);
+                    dp[r] = v;
+                }
+                if (col == 0) *reinterpret_cast<float4 *>(m.dspl + tt * A16 + 16 * mt + 4 * q) = make_float4(dp[0], dp[1], dp[2], dp[3]);
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) m.dFl[(prt * TT + tl) * 16 + 4 * q + r] = dFacc[r];
+    __syncthreads();
+    float *dsp_out = dsp_part + ((int64_t)blockIdx.x * B + b) * A;
+    for (int a = tid; a < A; a += blockDim.x)
+        dsp_out[a] = (m.dspl[a] + m.dspl[A16 + a]) + (m.dspl[2 * A16 + a] + m.dspl[3 * A16 + a]);
+    for (int i = tid; i < nrows * NCH; i += blockDim.x) {
+        const int r = i / NCH, c = i - r * NCH;
+        float v = 0.f;
+#pragma unroll
+        for (int p = 0; p < E2P; ++p) v += m.dFl[(p * TT + r) * 16 + c];
+        dF_s[((int64_t)b * T + t0) * NCH + i] = v;
+    }
+}
+
+static size_t energy_bwd2_smem(int A) {
+    const int A16 = (A + 15) & ~15;
+    return sizeof(float) * (size_t)(A16 * 14 + TT * 12 + 64 + 4 * A16 + E2P * TT * 16);
+}
+
 static bool al16(const void *p) { return (((uintptr_t)p) & 15) == 0; }
 
 extern "C" int64_t asr_attdec_ws_floats(int B, int T, int E, int Hd, int L) {
-    (void)E; (void)Hd; (void)L;
-    return (int64_t)B * T + 64;
+    (void)E; (void)L;
+    const int64_t A16 = (2 * Hd + 15) & ~15;
+    return (int64_t)B * T + 64 + A16 * 13 + 64;
 }
 
 struct GreedyParams {
@@ -424,14 +737,31 @@ static int run_attdec_fwd(const asr_attdec_fwd_args *a, const GreedyParams *gp, 
         attr_set = true;
     }
     const int64_t BH = (int64_t)B * Hd, BT = (int64_t)B * T, BA = (int64_t)B * A, BE = (int64_t)B * E;
+    const int A16p = (A + 15) & ~15;
     float *e_buf = a->ws;
+    float *tab = a->ws + BT + 64;            // padded W_fe / w_ee tables of the v2 energy kernel
     ASR_CHECK_HIP(hipMemsetAsync(a->S, 0, sizeof(float) * BH, st));
     ASR_CHECK_HIP(hipMemsetAsync(a->C, 0, sizeof(float) * BH, st));
     ASR_CHECK_HIP(hipMemsetAsync(a->sproj, 0, sizeof(float) * BA, st));
     const int vecPH = al16(a->PH) && A % 4 == 0;
+    const size_t esm2 = energy_fwd2_smem(A);
+    const bool use_v2 = vecPH && esm2 <= 150 * 1024;
+    const char *dbg_env = getenv("ASR_ATT_DBG");   // timing experiments only
+    const int att_dbg = dbg_env ? atoi(dbg_env) : 0;
+    if (use_v2) {
+        static thread_local bool attr2 = false;
+        if (!attr2) {
+            ASR_CHECK_HIP(hipFuncSetAttribute((const void *)energy_fwd2_kernel,
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+            attr2 = true;
+        }
+    }
     const int vecH = al16(a->hbatch) && E % 4 == 0;
     const int vecS = al16(a->S) && al16(a->W_se) && al16(a->W_ss) && Hd % 4 == 0;
     const int vecG = al16(a->g) && al16(a->W_gs) && E % 4 == 0;
+    if (use_v2)
+        hipLaunchKernelGGL(e2_prep_kernel, dim3(cdiv((int64_t)A16p * 12, 256)), dim3(256), 0, st, a->w_ee, a->W_fe,
+                           A, A16p, tab);
     for (int s = 0; s < L; ++s) {
         const float *S_s = a->S + s * BH;
         float *sp_s = a->sproj + s * BA;
@@ -439,10 +769,17 @@ static int run_attdec_fwd(const asr_attdec_fwd_args *a, const GreedyParams *gp, 
             hipLaunchKernelGGL(sproj_kernel, dim3(cdiv(A, 16), cdiv(B, 16)), dim3(256), 0, st, S_s, a->W_se,
                                sp_s, B, Hd, A, vecS);
         }
-        hipLaunchKernelGGL(energy_fwd_kernel, dim3(cdiv(T, TT), B), dim3(EW * 64), esm, st, a->PH,
-                           s > 0 ? a->alpha + (s - 1) * BT : (const float *)nullptr,
-                           s > 0 ? (const float *)sp_s : (const float *)nullptr, a->w_ee, a->W_fe, a->conv_w,
-                           a->lengths, e_buf, a->Fc + (int64_t)s * BT * NCH, T, A, vecPH);
+        if (use_v2) {
+            hipLaunchKernelGGL(energy_fwd2_kernel, dim3(cdiv(T, TT), B), dim3(E2W * 64), esm2, st, a->PH,
+                               s > 0 ? a->alpha + (s - 1) * BT : (const float *)nullptr,
+                               s > 0 ? (const float *)sp_s : (const float *)nullptr, (const float *)tab,
+                               a->conv_w, a->lengths, e_buf, a->Fc + (int64_t)s * BT * NCH, T, A, att_dbg);
+        } else {
+            hipLaunchKernelGGL(energy_fwd_kernel, dim3(cdiv(T, TT), B), dim3(EW * 64), esm, st, a->PH,
+                               s > 0 ? a->alpha + (s - 1) * BT : (const float *)nullptr,
+                               s > 0 ? (const float *)sp_s : (const float *)nullptr, a->w_ee, a->W_fe,
+                               a->conv_w, a->lengths, e_buf, a->Fc + (int64_t)s * BT * NCH, T, A, vecPH);
+        }
         hipLaunchKernelGGL(ctx_kernel, dim3(cdiv(E, 64), B), dim3(256), sizeof(float) * T, st, e_buf,
                            a->hbatch, a->lengths, a->alpha + s * BT, a->g + s * BE, T, E, vecH);
         if (gp) {
@@ -865,6 +1202,7 @@ extern "C" int64_t asr_attdec_bwd_ws_floats(int B, int T, int E, int Hd, int L) 
     n += (int64_t)B * T + 64;                    // dalpha
     n += (int64_t)B * Hd + 64;                   // dC carry
     n += nt * B * A + 64;                        // dsp partials
+    n += ((A + 15) & ~15) * 13 + 64;             // padded W_fe / w_ee tables
     int64_t post = nt * B * A * 11 + A * 11 + 64 + asr_colsum_ws_floats((int)(nt * B), (int)(A * 11)) + 64;
     int64_t conv = (int64_t)(L > 1 ? L - 1 : 1) * B * NCH * KW + 64 +
                    asr_colsum_ws_floats((L > 1 ? L - 1 : 1) * B, NCH * KW) + 64;
@@ -904,13 +1242,28 @@ extern "C" int asr_attdec_bwd(const asr_attdec_bwd_args *a, void *stream) {
     float *dalpha = w;            w += BT + 64;
     float *dC = w;                w += BH + 64;
     float *dsp_part = w;          w += nt * BA + 64;
+    const int A16p = (A + 15) & ~15;
+    float *tab = w;               w += (int64_t)A16p * 13 + 64;
     float *post = w;
     ASR_CHECK_HIP(hipMemsetAsync(dC, 0, sizeof(float) * BH, st));
     const int vecPH = al16(f->PH) && A % 4 == 0;
+    const size_t esm2 = energy_bwd2_smem(A);
+    const bool use_v2 = vecPH && esm2 <= 150 * 1024;
+    if (use_v2) {
+        static thread_local bool attr2 = false;
+        if (!attr2) {
+            ASR_CHECK_HIP(hipFuncSetAttribute((const void *)energy_bwd2_kernel,
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+            attr2 = true;
+        }
+    }
     const int vecH = al16(f->hbatch) && E % 4 == 0;
     const int vecT = Hd % 4 == 0 && al16(a->drec) && al16(a->dyp) && al16(dsp_part) && al16(a->W_ssT) &&
                      al16(a->W_syT) && al16(a->W_seT) && al16(a->W_gsT) && al16(a->W_gyT);
 
+    if (use_v2)
+        hipLaunchKernelGGL(e2_prep_kernel, dim3(cdiv((int64_t)A16p * 12, 256)), dim3(256), 0, st, f->w_ee, f->W_fe,
+                           A, A16p, tab);
     for (int s = L - 1; s >= 0; --s) {
         const bool has_next = s + 1 < L;
         hipLaunchKernelGGL(dscell_kernel, dim3(cdiv(Hd, 16), cdiv(B, 16)), dim3(1024), 0, st, s, L,
@@ -927,11 +1280,19 @@ extern "C" int asr_attdec_bwd(const asr_attdec_bwd_args *a, void *stream) {
                            (const float *)(a->dg + s * BE),
                            has_next ? (const float *)(a->dF + (s + 1) * BT * NCH) : (const float *)nullptr,
                            f->conv_w, f->lengths, dalpha, T, E, vecH);
-        hipLaunchKernelGGL(energy_bwd_kernel, dim3(cdiv(T, TT), B), dim3(EW * 64), esm, st, f->PH,
-                           (const float *)(f->alpha + s * BT), (const float *)dalpha,
-                           (const float *)(f->sproj + s * BA), f->w_ee, f->W_fe,
-                           (const float *)(f->Fc + s * BT * NCH), f->lengths, a->de + s * BT,
-                           a->dF + s * BT * NCH, dsp_part, B, T, A, vecPH);
+        if (use_v2) {
+            hipLaunchKernelGGL(energy_bwd2_kernel, dim3(cdiv(T, TT), B), dim3(E2W * 64), esm2, st, f->PH,
+                               (const float *)(f->alpha + s * BT), (const float *)dalpha,
+                               (const float *)(f->sproj + s * BA), (const float *)tab,
+                               (const float *)(f->Fc + s * BT * NCH), f->lengths, a->de + s * BT,
+                               a->dF + s * BT * NCH, dsp_part, B, T, A);
+        } else {
+            hipLaunchKernelGGL(energy_bwd_kernel, dim3(cdiv(T, TT), B), dim3(EW * 64), esm, st, f->PH,
+                               (const float *)(f->alpha + s * BT), (const float *)dalpha,
+                               (const float *)(f->sproj + s * BA), f->w_ee, f->W_fe,
+                               (const float *)(f->Fc + s * BT * NCH), f->lengths, a->de + s * BT,
+                               a->dF + s * BT * NCH, dsp_part, B, T, A, vecPH);
+        }
     }
     // dsp_0 (needed for dW_se = sum_s dsp_s^T S_s; S_0 = 0 so only for completeness): reduce the partials
     {

@@ -175,22 +175,36 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    if os.environ.get("ASR_BENCH_ONE_DEVICE"):      # rehearsal: every rank on GPU 0 (gloo only)
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        backend = os.environ.get("ASR_BENCH_BACKEND", "nccl")     # "gloo": rehearsal on a 1-GPU box
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     from asr_amd.Loss.label_smoothing import label_smoothing_loss
     from asr_amd.Models.AttModel import AttModel
     from asr_amd.parallel import BucketedGradReducer
 
+    verbose = bool(os.environ.get("ASR_BENCH_VERBOSE"))
+
+    def log(msg):
+        if verbose:
+            print(f"[bench rank {rank}] {time.strftime('%H:%M:%S')} {msg}", file=sys.stderr, flush=True)
+
     hp = make_hp(encoder_dropout=args.dropout)
     torch.manual_seed(1234)                      # identical weights on every rank
     model = AttModel(hp).to(dev).train()
+    log('model built')
     reducer = BucketedGradReducer(model)
     reducer.broadcast_parameters()
+    log('parameters broadcast')
     x, lengths, tgt, tl = make_batch(hp, dev, seed=1234 + rank)
     frames = make_batch.mel_frames
     opt = torch.optim.Adam(model.parameters(), lr=hp.lr, weight_decay=1e-5)
@@ -211,9 +225,11 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+    for i in range(args.warmup):
         step()
+        log(f'warm-up step {i} enqueued')
     barrier()
+    log('warm-up done')
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = step()

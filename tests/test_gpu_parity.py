@@ -193,7 +193,8 @@ def test_persistent_and_stepwise_recurrence_agree():
 
 
 @pytest.mark.parametrize("B,T,He,Hd,V,L,lens", [(3, 17, 8, 8, 11, 5, [17, 9, 4]), (4, 70, 6, 10, 13, 6, [70, 64, 65, 1]),
-                                                (2, 130, 16, 320, 50, 4, [130, 77]), (17, 150, 12, 16, 9, 3, None)])
+                                                (2, 130, 16, 320, 50, 4, [130, 77]), (17, 150, 12, 16, 9, 3, None),
+                                                (3, 40, 5, 9, 7, 4, [40, 22, 7])])
 def test_decoder_vs_oracle(B, T, He, Hd, V, L, lens):
     from asr_amd.Models.decoder import Decoder
     from oracle import ref_model as R
@@ -351,3 +352,71 @@ def test_full_size_properties():
                 p.add_(dirs[k], alpha=-sgn * eps)
         fd = (vals[0] - vals[1]) / (2 * eps)
     assert abs(fd - analytic) / max(abs(analytic), 1e-6) < 2e-2, (fd, analytic)
+
+
+def test_config1_speech_commands_shape_vs_oracle():
+    """BASELINE config 1 (the reference's CPU-runnable case): B=8, 98 frames of 40-dim
+    fbank, stack 3 -> T=32, D=120, template widths (H=320, 5 layers), V=37, L=3."""
+    from asr_amd.Loss.label_smoothing import label_smoothing_loss
+    from asr_amd.utils.utils import frame_stacking
+    from oracle import ref_model as R
+    dev = _dev()
+    hp = R.make_hp(lmfb_dim=40, num_classes=37, encoder_dropout=0.0)
+    torch.manual_seed(1234)
+    ref = R.AttModel(hp)
+    B, L = 8, 3
+    mel = torch.randn(B, 98, 40)
+    mel_len = torch.full((B,), 98, dtype=torch.int64)
+    tgt = torch.randint(0, 37, (B, L))
+    tl = torch.full((B,), L, dtype=torch.int64)
+    x, lengths = frame_stacking(mel, mel_len, 3)
+    x = x.contiguous()
+    xr = x.clone().requires_grad_(True)
+    lr = R.label_smoothing_loss(ref(xr, lengths, tgt), tgt, tl)
+    lr.backward()
+    m = _build(hp, ref.state_dict())
+    xd = x.to(dev).requires_grad_(True)
+    loss = label_smoothing_loss(m(xd, lengths, tgt.to(dev)), tgt.to(dev), tl.to(dev))
+    loss.backward()
+    assert abs(float(loss) - float(lr)) / abs(float(lr)) < LOSS_TOL
+    assert rel_err(xd.grad.cpu(), xr.grad) < GRAD_TOL
+    for (k, p), (_, q) in zip(m.named_parameters(), ref.named_parameters()):
+        assert rel_err(p.grad.cpu(), q.grad) < GRAD_TOL, k
+
+
+def test_dropout_between_layers():
+    """encoder_dropout > 0 (template default 0.2): the mask is Bernoulli(1-p), scaled by
+    1/(1-p), the same mask is applied in the backward, and eval() disables it."""
+    import ctypes as C
+    from asr_amd import _lib
+    lib = _lib.load()
+    dev = _dev()
+    n, p = 1 << 20, 0.2
+    x = torch.randn(n, device=dev)
+    y = torch.empty_like(x)
+    mask = torch.empty(n, device=dev, dtype=torch.uint8)
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    _lib.check(lib.asr_dropout_fwd(x.data_ptr(), y.data_ptr(), mask.data_ptr(), n, C.c_float(p), C.c_uint64(99), st))
+    keep = mask.float().mean().item()
+    assert abs(keep - (1 - p)) < 5e-3
+    assert torch.equal(y, torch.where(mask.bool(), x * (1.0 / (1.0 - p)), torch.zeros_like(x)))
+    dx = torch.empty_like(x)
+    _lib.check(lib.asr_dropout_bwd(y.data_ptr(), mask.data_ptr(), dx.data_ptr(), n, C.c_float(p), st))
+    assert torch.equal(dx, torch.where(mask.bool(), y * (1.0 / (1.0 - p)), torch.zeros_like(x)))
+    # through the module: train() differs from eval(), eval() is deterministic
+    from asr_amd.Models.encoder import Encoder
+    from oracle import ref_model as R
+    hp = R.make_hp(lmfb_dim=8, frame_stacking=1, num_hidden_nodes=16, num_encoder_layer=3, encoder_dropout=0.5)
+    torch.manual_seed(5)
+    enc = Encoder(hp).to(dev)
+    xin = torch.randn(4, 20, 8, device=dev)
+    lens = torch.tensor([20, 15, 9, 20])
+    enc.eval()
+    a, b = enc(xin, lens), enc(xin, lens)
+    assert torch.equal(a, b)
+    enc.train()
+    c = enc(xin, lens)
+    assert not torch.equal(a, c)
+    xg = xin.clone().requires_grad_(True)
+    enc(xg, lens).sum().backward()
+    assert torch.isfinite(xg.grad).all()
