@@ -12,7 +12,7 @@ import math
 import torch
 import torch.nn as nn
 
-from .. import _lib, ops
+from .. import _lib, ops, streams
 from .._lib import AttDecBwdArgs, AttDecFwdArgs, check
 from .attention import Attention
 
@@ -125,7 +125,18 @@ class _AttDecFunction(torch.autograd.Function):
                          ws=ws).items():
             setattr(a, k, v.data_ptr())
         check(lib.asr_attdec_bwd(C.byref(a), _stream()))
-        # hoisted weight gradients: (L*B)-row TN GEMMs over the saved per-step tensors
+        dPH2 = dPH.view(B * T, A)
+        h2 = hbatch.view(B * T, E)
+        # critical path first: d hbatch = dPH W_he + sum_s alpha_s (x) dg_s  (per utterance:
+        # (T x L) @ (L x E)) feeds the encoder backward
+        dh = None
+        if ctx.needs_input_grad[0]:
+            dh = torch.empty(B, T, E, **f32)
+            ops.matmul_nn(dPH2, P["W_he"], dh.view(B * T, E))
+            ops.sgemm(alpha, dg, dh, T, E, L, a_mode=1, a_stride=B * T, b_mode=1, b_stride=B * E, c_stride=E,
+                      accumulate=True, nbatch=B, batch_a=T, batch_b=E, batch_c=T * E)
+        # hoisted weight gradients: (L*B)-row TN GEMMs over the saved per-step tensors; nothing
+        # downstream reads them -> side stream, overlapping the encoder's backward recurrence
         S_in = S[:L].view(L * B, Hd)
         g2, drec2, dyp2, dsp2 = g.view(L * B, E), drec.view(L * B, 4 * Hd), dyp.view(L * B, Hd), dsp.view(L * B, A)
 
@@ -134,31 +145,24 @@ class _AttDecFunction(torch.autograd.Function):
             ops.matmul_tn(a2, b2, out)
             return out
 
-        G["W_gs"] = tn(drec2, g2)
-        G["W_ss"] = tn(drec2, S_in)
-        G["b_gs"] = torch.empty(4 * Hd, **f32)
-        ops.colsum(drec2, G["b_gs"])
-        G["W_gy"] = tn(dyp2, g2)
-        G["W_sy"] = tn(dyp2, S_in)
-        G["b_gy"] = torch.empty(Hd, **f32)
-        ops.colsum(dyp2, G["b_gy"])
-        G["W_se"] = tn(dsp2, S_in)
-        G["Emb"] = torch.empty(V, 4 * Hd, **f32)
-        ops.scatter_rows(drec2, t["targets"].t().contiguous().view(-1), G["Emb"])
-        dPH2 = dPH.view(B * T, A)
-        h2 = hbatch.view(B * T, E)
-        G["W_he"] = tn(dPH2, h2)
-        G["b_he"] = torch.empty(A, **f32)
-        ops.colsum(dPH2, G["b_he"])
+        idx = t["targets"].t().contiguous().view(-1)
+        with streams.on_side(dev, S, g, drec, dyp, dsp, dPH, hbatch, idx):
+            G["W_gs"] = tn(drec2, g2)
+            G["W_ss"] = tn(drec2, S_in)
+            G["b_gs"] = torch.empty(4 * Hd, **f32)
+            ops.colsum(drec2, G["b_gs"])
+            G["W_gy"] = tn(dyp2, g2)
+            G["W_sy"] = tn(dyp2, S_in)
+            G["b_gy"] = torch.empty(Hd, **f32)
+            ops.colsum(dyp2, G["b_gy"])
+            G["W_se"] = tn(dsp2, S_in)
+            G["Emb"] = torch.empty(V, 4 * Hd, **f32)
+            ops.scatter_rows(drec2, idx, G["Emb"])
+            G["W_he"] = tn(dPH2, h2)
+            G["b_he"] = torch.empty(A, **f32)
+            ops.colsum(dPH2, G["b_he"])
         G["w_ee"], G["W_fe"], G["conv_w"] = dw_ee, dW_fe, dconv
         G["W_yy"], G["b_yy"] = dW_yy, db_yy
-        # d hbatch = dPH W_he + sum_s alpha_s (x) dg_s   (per utterance: (T x L) @ (L x E))
-        dh = None
-        if ctx.needs_input_grad[0]:
-            dh = torch.empty(B, T, E, **f32)
-            ops.matmul_nn(dPH2, P["W_he"], dh.view(B * T, E))
-            ops.sgemm(alpha, dg, dh, T, E, L, a_mode=1, a_stride=B * T, b_mode=1, b_stride=B * E, c_stride=E,
-                      accumulate=True, nbatch=B, batch_a=T, batch_b=E, batch_c=T * E)
         ctx.t = ctx.U = None
         return (dh, None, None) + tuple(G[n] for n in _AttDecFunction.NAMES)
 

@@ -13,7 +13,7 @@ import math
 import torch
 import torch.nn as nn
 
-from .. import _lib, ops
+from .. import _lib, ops, streams
 from .._lib import check
 
 
@@ -132,34 +132,7 @@ class _BLSTMLayerFunction(torch.autograd.Function):
                                 lengths_dev.data_ptr(), dc_ws.data_ptr(), T, B, H,
                                 0 if ws is None else ws.data_ptr(), st))
         dG = G.view(T * B, 8 * H)                  # now d loss / d pre-activation gates (0 at padding)
-        db = torch.empty(8 * H, **f32)
-        ops.colsum(dG, db)                         # b_ih and b_hh receive the same column sums
-        hout_two = (B, ho_b, ho_t)                 # row (t*B + b) <-> Hout element offset
-        grads = {}
-        for d in range(2):
-            # dW_hh[d] = sum_t dG_t^T h_{t-1}: forward pairs (t, t-1), reverse pairs (t, t+1);
-            # padded rows of dG and Hout are zero, so ragged lengths need no masking here
-            gW = torch.empty(4 * H, H, **f32)
-            if T > 1:
-                K = (T - 1) * B
-                sk = ops.pick_splitk(4 * H, H, K)
-                if sk > 1:
-                    gW.zero_()
-                a_off = d * 4 * H + (B * 8 * H if d == 0 else 0)
-                b_off = d * H + (0 if d == 0 else ho_t)
-                ops.sgemm(dG, Hout, gW, 4 * H, H, K, a_mode=1, a_stride=8 * H, a_off=a_off, b_mode=1,
-                          b_two=hout_two, b_off=b_off, c_stride=H, splitk=sk)
-            else:
-                gW.zero_()
-            # dW_ih[d] = dG[:, d]^T X
-            gWi = torch.empty(4 * H, D, **f32)
-            K = T * B
-            sk = ops.pick_splitk(4 * H, D, K)
-            if sk > 1:
-                gWi.zero_()
-            ops.sgemm(dG, inp, gWi, 4 * H, D, K, a_mode=1, a_stride=8 * H, a_off=d * 4 * H, b_mode=1,
-                      b_two=in_two, c_stride=D, splitk=sk)
-            grads[d] = (gWi, gW, db[d * 4 * H:(d + 1) * 4 * H], db[d * 4 * H:(d + 1) * 4 * H].clone())
+        # critical path first: the input gradient feeds the next layer's recurrence
         dIn = None
         if ctx.needs_input_grad[0]:
             # dX = dG[:, fwd] W_ih_f + dG[:, rev] W_ih_r, written in the input's own layout
@@ -167,6 +140,37 @@ class _BLSTMLayerFunction(torch.autograd.Function):
             for d, w_ih in enumerate((w_ih_f, w_ih_r)):
                 ops.sgemm(dG, w_ih, dIn, T * B, D, 4 * H, a_stride=8 * H, a_off=d * 4 * H, b_mode=1,
                           b_stride=D, c_two=in_two, accumulate=(d == 1))
+        # weight / bias gradients: nothing downstream reads them -> side stream, overlapping the
+        # next layer's (latency-bound) recurrence kernel
+        hout_two = (B, ho_b, ho_t)                 # row (t*B + b) <-> Hout element offset
+        grads = {}
+        with streams.on_side(dev, G, inp, Hout):
+            db = torch.empty(8 * H, **f32)
+            ops.colsum(dG, db)                     # b_ih and b_hh receive the same column sums
+            for d in range(2):
+                # dW_hh[d] = sum_t dG_t^T h_{t-1}: forward pairs (t, t-1), reverse pairs (t, t+1);
+                # padded rows of dG and Hout are zero, so ragged lengths need no masking here
+                gW = torch.empty(4 * H, H, **f32)
+                if T > 1:
+                    K = (T - 1) * B
+                    sk = ops.pick_splitk(4 * H, H, K)
+                    if sk > 1:
+                        gW.zero_()
+                    a_off = d * 4 * H + (B * 8 * H if d == 0 else 0)
+                    b_off = d * H + (0 if d == 0 else ho_t)
+                    ops.sgemm(dG, Hout, gW, 4 * H, H, K, a_mode=1, a_stride=8 * H, a_off=a_off, b_mode=1,
+                              b_two=hout_two, b_off=b_off, c_stride=H, splitk=sk)
+                else:
+                    gW.zero_()
+                # dW_ih[d] = dG[:, d]^T X
+                gWi = torch.empty(4 * H, D, **f32)
+                K = T * B
+                sk = ops.pick_splitk(4 * H, D, K)
+                if sk > 1:
+                    gWi.zero_()
+                ops.sgemm(dG, inp, gWi, 4 * H, D, K, a_mode=1, a_stride=8 * H, a_off=d * 4 * H, b_mode=1,
+                          b_two=in_two, c_stride=D, splitk=sk)
+                grads[d] = (gWi, gW, db[d * 4 * H:(d + 1) * 4 * H], db[d * 4 * H:(d + 1) * 4 * H].clone())
         return (dIn, None, None, None, None) + grads[0] + grads[1]
 
 

@@ -13,7 +13,7 @@ The 1/world_size of DDP's mean is applied with asr_scale when the bucket lands.
 import torch
 import torch.distributed as dist
 
-from . import ops
+from . import ops, streams
 
 
 class BucketedGradReducer:
@@ -60,6 +60,8 @@ class BucketedGradReducer:
         if self.flat[bi] is None or self.flat[bi].numel() != n:
             self.flat[bi] = torch.empty(n, device=ps[0].device, dtype=torch.float32)
         flat = self.flat[bi]
+        if ps[0].is_cuda:
+            streams.wait_side(ps[0].device)      # weight gradients are produced on the side stream
         o = 0
         for p in ps:
             flat[o:o + p.numel()].copy_(p.grad.reshape(-1))

@@ -1,0 +1,77 @@
+"""Side stream for work that is off the backward's critical path.
+
+The backward of the path is a chain of latency-bound kernels (the BLSTM and decoder
+recurrences occupy a fraction of the CUs and mostly wait on each other); the weight
+gradients, on the other hand, are large independent GEMMs that nothing in the rest of
+the backward reads.  They are therefore enqueued on a second HIP stream, ordered after
+the kernel that produces their input by an event, and run concurrently with the next
+recurrence.  One callback at the end of the autograd pass makes the main stream wait
+for the side stream, so every ``.grad`` is complete when ``backward()`` returns control
+to the caller's stream.
+"""
+import os
+import threading
+
+import torch
+
+ENABLED = os.environ.get("ASR_SIDE_STREAM", "1") != "0"
+_streams = {}
+_tls = threading.local()
+
+
+def side_stream(device):
+    s = _streams.get(device.index)
+    if s is None:
+        s = torch.cuda.Stream(device=device)
+        _streams[device.index] = s
+    return s
+
+
+def _join(device):
+    torch.cuda.current_stream(device).wait_stream(side_stream(device))
+    _tls.armed = False
+
+
+def arm_join(device):
+    """Queue (once per backward pass) the callback that joins the side stream."""
+    if getattr(_tls, "armed", False):
+        return
+    _tls.armed = True
+    torch.autograd.Variable._execution_engine.queue_callback(lambda: _join(device))
+
+
+def wait_side(device):
+    """Make the current stream wait for everything enqueued on the side stream so far."""
+    if device.index in _streams:
+        torch.cuda.current_stream(device).wait_stream(_streams[device.index])
+
+
+class on_side:
+    """with on_side(device, *tensors): ... -- run the block on the side stream, ordered after
+    everything enqueued on the current stream so far; `tensors` were allocated on the main
+    stream and are read by the block (their memory must not be recycled under it)."""
+
+    def __init__(self, device, *tensors):
+        self.device = device
+        self.tensors = tensors
+        self.ctx = None
+
+    def __enter__(self):
+        if not ENABLED:
+            return self
+        side = side_stream(self.device)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(self.device))
+        side.wait_event(ev)
+        for t in self.tensors:
+            if t is not None:
+                t.record_stream(side)
+        arm_join(self.device)
+        self.ctx = torch.cuda.stream(side)
+        self.ctx.__enter__()
+        return self
+
+    def __exit__(self, *exc):
+        if self.ctx is not None:
+            self.ctx.__exit__(*exc)
+        return False
