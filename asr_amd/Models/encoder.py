@@ -9,6 +9,7 @@ input projections of all frames are MFMA GEMMs (asr_sgemm).
 """
 import ctypes as C
 import math
+import os
 
 import torch
 import torch.nn as nn
@@ -75,16 +76,51 @@ def persistent_error_flags():
     return any(bool(ws.view(torch.int32)[ERR_WORD].item()) for ws in _WS.values())
 
 
+# Chunk pipelining (DESIGN.md "overlap"): a layer's recurrence can run as PIPE_CHUNKS launches
+# over consecutive step ranges; after each launch the frames that are final -- the forward
+# direction's first steps and the reverse direction's last frames -- are handed to a second
+# stream, which in the forward pass applies the inter-layer dropout and accumulates their part of
+# the NEXT layer's input projection, and in the backward pass accumulates their part of dX.
+# Measured on MI355X (config 2): the chunked launches themselves cost +7 us per layer, but GEMM
+# waves sharing the recurrence's CUs stretch every recurrence step by ~15% and the GEMMs by ~40%,
+# which cancels what the overlap hides (39.3 ms/step off, 39.5-40.0 ms on) -- so the default is
+# off (1); ASR_PIPE_CHUNKS=4 turns it on.
+PIPE_CHUNKS = int(os.environ.get("ASR_PIPE_CHUNKS", "1"))
+PIPE_MIN_T = 64
+PIPE_FWD = os.environ.get("ASR_PIPE_FWD", "1") != "0"
+PIPE_BWD = os.environ.get("ASR_PIPE_BWD", "1") != "0"
+
+
+def _chunks(T, n):
+    tc = -(-T // n)
+    return [(s0, min(T, s0 + tc)) for s0 in range(0, T, tc)]
+
+
+class _Next:
+    """What a layer needs to prepare its successor's input: the successor's input weights and the
+    dropout between the two.  Plain attribute bag, invisible to autograd on purpose: the successor
+    computes the gradients of these weights itself from its saved input."""
+
+    def __init__(self, w_ih_f, b_ih_f, b_hh_f, w_ih_r, b_ih_r, b_hh_r, p, seed):
+        self.w = (w_ih_f.detach(), w_ih_r.detach())
+        self.b = (b_ih_f.detach(), b_hh_f.detach(), b_ih_r.detach(), b_hh_r.detach())
+        self.p, self.seed = p, seed
+        self.G = None            # filled by the producing layer: (T,B,2,4H) pre-activations
+
+
 class _BLSTMLayerFunction(torch.autograd.Function):
     """One bidirectional layer.  Input is (B,T,D) batch-major for the first layer
     and (T,B,D) time-major otherwise; output is (B,T,2H) batch-major for the last
     layer and (T,B,2H) time-major otherwise (one time step = one contiguous slab
     for the recurrence kernels).  One autograd node per layer, so a layer's
     gradients are final -- and its all-reduce bucket can start -- while the layers
-    below are still in their backward."""
+    below are still in their backward.
+
+    pre: _Next whose .G holds this layer's input projection (made by the layer below) or None;
+    nxt: _Next to fill for the layer above (the output is then already dropped out) or None."""
 
     @staticmethod
-    def forward(ctx, inp, lengths_dev, first, last, H, w_ih_f, w_hh_f, b_ih_f, b_hh_f, w_ih_r, w_hh_r,
+    def forward(ctx, inp, lengths_dev, first, last, H, pre, nxt, w_ih_f, w_hh_f, b_ih_f, b_hh_f, w_ih_r, w_hh_r,
                 b_ih_r, b_hh_r):
         lib = _lib.load()
         inp = inp.contiguous()
@@ -96,50 +132,126 @@ class _BLSTMLayerFunction(torch.autograd.Function):
             in_two = (0, D, 0)
         dev = inp.device
         st = _stream()
-        G = torch.empty(T, B, 2, 4 * H, device=dev, dtype=torch.float32)
-        Cs = torch.empty(T, B, 2, H, device=dev, dtype=torch.float32)
-        for d, (w_ih, b_ih, b_hh) in enumerate(((w_ih_f, b_ih_f, b_hh_f), (w_ih_r, b_ih_r, b_hh_r))):
-            ops.sgemm(inp, w_ih, G, T * B, 4 * H, D, a_two=in_two, b_stride=D, c_stride=8 * H,
-                      c_off=d * 4 * H, bias1=b_ih, bias2=b_hh)
+        f32 = dict(device=dev, dtype=torch.float32)
+        Cs = torch.empty(T, B, 2, H, **f32)
+        if pre is not None and pre.G is not None:
+            G, pre.G = pre.G, None
+        else:
+            G = torch.empty(T, B, 2, 4 * H, **f32)
+            for d, (w_ih, b_ih, b_hh) in enumerate(((w_ih_f, b_ih_f, b_hh_f), (w_ih_r, b_ih_r, b_hh_r))):
+                ops.sgemm(inp, w_ih, G, T * B, 4 * H, D, a_two=in_two, b_stride=D, c_stride=8 * H,
+                          c_off=d * 4 * H, bias1=b_ih, bias2=b_hh)
         W_hh = torch.cat([w_hh_f, w_hh_r], 0)      # [2][4H][H]
         if last:
-            Hout = torch.empty(B, T, 2 * H, device=dev, dtype=torch.float32)
+            Hout = torch.empty(B, T, 2 * H, **f32)
             ho_t, ho_b = 2 * H, T * 2 * H
         else:
-            Hout = torch.empty(T, B, 2 * H, device=dev, dtype=torch.float32)
+            Hout = torch.empty(T, B, 2 * H, **f32)
             ho_t, ho_b = B * 2 * H, 2 * H
         ws = _persist_ws(lib, B, H, dev)
-        check(lib.asr_blstm_fwd(W_hh.data_ptr(), G.data_ptr(), Cs.data_ptr(), Hout.data_ptr(), ho_t, ho_b,
-                                lengths_dev.data_ptr(), T, B, H, 0 if ws is None else ws.data_ptr(), st))
+        wsp = 0 if ws is None else ws.data_ptr()
+        nch = PIPE_CHUNKS if (streams.ENABLED and T >= PIPE_MIN_T) else 1
+        out, mask = Hout, None
+        if nxt is None or last or nch <= 1:
+            check(lib.asr_blstm_fwd(W_hh.data_ptr(), G.data_ptr(), Cs.data_ptr(), Hout.data_ptr(), ho_t, ho_b,
+                                    lengths_dev.data_ptr(), T, B, H, wsp, st))
+            assert nxt is None, "a layer is only asked to prepare its successor when pipelining is on"
+        else:
+            p, seed = nxt.p, nxt.seed
+            W_n = torch.cat(nxt.w, 0)                                            # [8H][2H]
+            b_n = torch.cat([nxt.b[0] + nxt.b[1], nxt.b[2] + nxt.b[3]], 0)      # [8H]
+            G_n = torch.empty(T, B, 2, 4 * H, **f32)
+            if p > 0.0:
+                out = torch.empty_like(Hout)
+                mask = torch.empty(Hout.numel(), device=dev, dtype=torch.uint8)
+            pipe = streams.pipe_stream(dev)
+            main = torch.cuda.current_stream(dev)
+            for t_ in (Hout, out, mask, G_n, W_n, b_n):
+                if t_ is not None:
+                    t_.record_stream(pipe)
+            pipe.wait_stream(main)
+            with torch.cuda.stream(pipe):
+                G_n.view(T * B, 8 * H).copy_(b_n.expand(T * B, 8 * H))
+            for s0, s1 in _chunks(T, nch):
+                check(lib.asr_blstm_fwd_range(W_hh.data_ptr(), G.data_ptr(), Cs.data_ptr(), Hout.data_ptr(), ho_t,
+                                              ho_b, lengths_dev.data_ptr(), T, B, H, s0, s1, wsp, st))
+                pipe.wait_stream(main)
+                with torch.cuda.stream(pipe):
+                    for d in range(2):
+                        t0, t1 = (s0, s1) if d == 0 else (T - s1, T - s0)
+                        rows = (t1 - t0) * B
+                        off = t0 * B * 2 * H + d * H
+                        if p > 0.0:
+                            check(lib.asr_dropout_fwd_block(Hout.data_ptr() + 4 * off, out.data_ptr() + 4 * off,
+                                                            mask.data_ptr() + off, rows, H, 2 * H, off,
+                                                            C.c_float(p), C.c_uint64(seed), _stream()))
+                        # G_next[t0:t1] += X[t0:t1, :, d-th half] W_next[:, d-th half]^T
+                        ops.sgemm(out, W_n, G_n, rows, 8 * H, H, a_stride=2 * H, a_off=off, b_stride=2 * H,
+                                  b_off=d * H, c_stride=8 * H, c_off=t0 * B * 8 * H, accumulate=True)
+            main.wait_stream(pipe)
+            nxt.G = G_n
         ctx.save_for_backward(inp, G, Cs, Hout, lengths_dev, w_ih_f, w_hh_f, w_ih_r, w_hh_r)
+        ctx.mask = mask
+        ctx.p = nxt.p if mask is not None else 0.0
         ctx.dims = (B, T, D, H, first, in_two, ho_t, ho_b)
-        return Hout
+        return out
 
     @staticmethod
-    def backward(ctx, dHout):
+    def backward(ctx, dOut):
         lib = _lib.load()
         B, T, D, H, first, in_two, ho_t, ho_b = ctx.dims
         inp, G, Cs, Hout, lengths_dev, w_ih_f, w_hh_f, w_ih_r, w_hh_r = ctx.saved_tensors
         dev = inp.device
         st = _stream()
-        dHout = dHout.contiguous()                 # same layout as Hout
+        dOut = dOut.contiguous()                   # same layout as Hout
         f32 = dict(device=dev, dtype=torch.float32)
+        if ctx.mask is not None:                   # the dropout this layer applied to its own output
+            dHout = torch.empty_like(dOut)
+            check(lib.asr_dropout_bwd(dOut.data_ptr(), ctx.mask.data_ptr(), dHout.data_ptr(), dOut.numel(),
+                                      C.c_float(ctx.p), st))
+        else:
+            dHout = dOut
         dc_ws = torch.empty(2 * B * H, **f32)
         W_hh = torch.cat([w_hh_f, w_hh_r], 0).view(2, 4 * H, H)
         W_hhT = ops.transpose(W_hh)                # [2][H][4H] (step-wise kernels)
         ws = _persist_ws(lib, B, H, dev)
-        check(lib.asr_blstm_bwd(W_hh.data_ptr(), W_hhT.data_ptr(), G.data_ptr(), Cs.data_ptr(), dHout.data_ptr(), ho_t, ho_b,
-                                lengths_dev.data_ptr(), dc_ws.data_ptr(), T, B, H,
-                                0 if ws is None else ws.data_ptr(), st))
-        dG = G.view(T * B, 8 * H)                  # now d loss / d pre-activation gates (0 at padding)
-        # critical path first: the input gradient feeds the next layer's recurrence
+        wsp = 0 if ws is None else ws.data_ptr()
+        dG = G.view(T * B, 8 * H)                  # becomes d loss / d pre-activation gates (0 at padding)
+        need_dx = ctx.needs_input_grad[0]
+        nch = PIPE_CHUNKS if (streams.ENABLED and PIPE_BWD and T >= PIPE_MIN_T and need_dx and not first) else 1
         dIn = None
-        if ctx.needs_input_grad[0]:
-            # dX = dG[:, fwd] W_ih_f + dG[:, rev] W_ih_r, written in the input's own layout
+        if nch <= 1:
+            check(lib.asr_blstm_bwd(W_hh.data_ptr(), W_hhT.data_ptr(), G.data_ptr(), Cs.data_ptr(), dHout.data_ptr(),
+                                    ho_t, ho_b, lengths_dev.data_ptr(), dc_ws.data_ptr(), T, B, H, wsp, st))
+            # critical path first: the input gradient feeds the next layer's recurrence
+            if need_dx:
+                # dX = dG[:, fwd] W_ih_f + dG[:, rev] W_ih_r, written in the input's own layout
+                dIn = torch.empty_like(inp)
+                for d, w_ih in enumerate((w_ih_f, w_ih_r)):
+                    ops.sgemm(dG, w_ih, dIn, T * B, D, 4 * H, a_stride=8 * H, a_off=d * 4 * H, b_mode=1,
+                              b_stride=D, c_two=in_two, accumulate=(d == 1))
+        else:
+            # time-major input (T,B,D): the rows of a frame range are contiguous in dG and dX
             dIn = torch.empty_like(inp)
-            for d, w_ih in enumerate((w_ih_f, w_ih_r)):
-                ops.sgemm(dG, w_ih, dIn, T * B, D, 4 * H, a_stride=8 * H, a_off=d * 4 * H, b_mode=1,
-                          b_stride=D, c_two=in_two, accumulate=(d == 1))
+            pipe = streams.pipe_stream(dev)
+            main = torch.cuda.current_stream(dev)
+            for t_ in (G, dIn):
+                t_.record_stream(pipe)
+            pipe.wait_stream(main)
+            with torch.cuda.stream(pipe):
+                dIn.zero_()
+            for s0, s1 in _chunks(T, nch):
+                check(lib.asr_blstm_bwd_range(W_hh.data_ptr(), W_hhT.data_ptr(), G.data_ptr(), Cs.data_ptr(),
+                                              dHout.data_ptr(), ho_t, ho_b, lengths_dev.data_ptr(),
+                                              dc_ws.data_ptr(), T, B, H, s0, s1, wsp, st))
+                pipe.wait_stream(main)
+                with torch.cuda.stream(pipe):
+                    for d, w_ih in enumerate((w_ih_f, w_ih_r)):
+                        t0, t1 = (T - s1, T - s0) if d == 0 else (s0, s1)
+                        ops.sgemm(dG, w_ih, dIn, (t1 - t0) * B, D, 4 * H, a_stride=8 * H,
+                                  a_off=t0 * B * 8 * H + d * 4 * H, b_mode=1, b_stride=D, c_stride=D,
+                                  c_off=t0 * B * D, accumulate=True)
+            main.wait_stream(pipe)
         # weight / bias gradients: nothing downstream reads them -> side stream, overlapping the
         # next layer's (latency-bound) recurrence kernel
         hout_two = (B, ho_b, ho_t)                 # row (t*B + b) <-> Hout element offset
@@ -171,7 +283,7 @@ class _BLSTMLayerFunction(torch.autograd.Function):
                 ops.sgemm(dG, inp, gWi, 4 * H, D, K, a_mode=1, a_stride=8 * H, a_off=d * 4 * H, b_mode=1,
                           b_two=in_two, c_stride=D, splitk=sk)
                 grads[d] = (gWi, gW, db[d * 4 * H:(d + 1) * 4 * H], db[d * 4 * H:(d + 1) * 4 * H].clone())
-        return (dIn, None, None, None, None) + grads[0] + grads[1]
+        return (dIn, None, None, None, None, None, None) + grads[0] + grads[1]
 
 
 class _DropoutFunction(torch.autograd.Function):
@@ -216,10 +328,18 @@ class Encoder(nn.Module):
         seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if p > 0.0 else 0
         h = x.float()
         flat = self.bi_lstm.flat()
+        T = h.shape[1]
+        pipelined = streams.ENABLED and PIPE_FWD and PIPE_CHUNKS > 1 and T >= PIPE_MIN_T
+        pre = None
         for layer in range(self.num_layers):
             last = layer == self.num_layers - 1
-            h = _BLSTMLayerFunction.apply(h, lengths_dev, layer == 0, last, self.hidden,
+            nxt = None
+            if pipelined and not last:
+                n = flat[8 * (layer + 1): 8 * (layer + 1) + 8]     # (w_ih, w_hh, b_ih, b_hh) x (fwd, rev)
+                nxt = _Next(n[0], n[2], n[3], n[4], n[6], n[7], p, seed + 7919 * layer)
+            h = _BLSTMLayerFunction.apply(h, lengths_dev, layer == 0, last, self.hidden, pre, nxt,
                                           *flat[8 * layer: 8 * layer + 8])
-            if p > 0.0 and not last:
+            if nxt is None and p > 0.0 and not last:
                 h = _DropoutFunction.apply(h, p, seed + 7919 * layer)
+            pre = nxt
         return h

@@ -72,6 +72,11 @@ SYMBOLS = {
     "asr_blstm_fwd": (C.c_int, [c_f, c_f, c_f, c_f, c_i64, c_i64, c_f, C.c_int, C.c_int, C.c_int, c_f, c_f]),
     "asr_blstm_bwd": (C.c_int, [c_f, c_f, c_f, c_f, c_f, c_i64, c_i64, c_f, c_f, C.c_int, C.c_int, C.c_int,
                                 c_f, c_f]),
+    "asr_blstm_fwd_range": (C.c_int, [c_f, c_f, c_f, c_f, c_i64, c_i64, c_f, C.c_int, C.c_int, C.c_int, C.c_int,
+                                      C.c_int, c_f, c_f]),
+    "asr_blstm_bwd_range": (C.c_int, [c_f, c_f, c_f, c_f, c_f, c_i64, c_i64, c_f, c_f, C.c_int, C.c_int, C.c_int,
+                                      C.c_int, C.c_int, c_f, c_f]),
+    "asr_dropout_fwd_block": (C.c_int, [c_f, c_f, c_f, c_i64, c_i64, c_i64, c_i64, C.c_float, C.c_uint64, c_f]),
     "asr_dropout_fwd": (C.c_int, [c_f, c_f, c_f, c_i64, C.c_float, C.c_uint64, c_f]),
     "asr_dropout_bwd": (C.c_int, [c_f, c_f, c_f, c_i64, C.c_float, c_f]),
     "asr_attdec_ws_floats": (c_i64, [C.c_int] * 5),

@@ -77,12 +77,13 @@ __global__ __launch_bounds__(256) void blstm_fwd_step_kernel(
 }
 
 static int blstm_fwd_steps(const float *W_hh, float *G, float *Cs, float *Hout, int64_t ho_t,
-                          int64_t ho_b, const int32_t *lengths, int T, int B, int H, void *stream) {
+                          int64_t ho_b, const int32_t *lengths, int T, int B, int H, int s0, int s1,
+                          void *stream) {
     hipStream_t st = (hipStream_t)stream;
     const int vec = (H % 4 == 0) && (ho_t % 4 == 0) && (ho_b % 4 == 0) && (((uintptr_t)Hout & 15) == 0) &&
                     (((uintptr_t)W_hh & 15) == 0);
     dim3 grid(cdiv(H, 4), 2, cdiv(B, 16));
-    for (int step = 0; step < T; ++step) {
+    for (int step = s0; step < s1; ++step) {
         hipLaunchKernelGGL(blstm_fwd_step_kernel, grid, dim3(256), 0, st, W_hh, G, Cs, Hout, ho_t, ho_b,
                            lengths, T, B, H, step, vec);
     }
@@ -151,12 +152,12 @@ __global__ __launch_bounds__(1024) void blstm_bwd_step_kernel(
 
 static int blstm_bwd_steps(const float *W_hhT, float *G, const float *Cs, const float *dHout,
                           int64_t dho_t, int64_t dho_b, const int32_t *lengths, float *dc_ws, int T,
-                          int B, int H, void *stream) {
+                          int B, int H, int s0, int s1, void *stream) {
     hipStream_t st = (hipStream_t)stream;
-    ASR_CHECK_HIP(hipMemsetAsync(dc_ws, 0, sizeof(float) * 2 * (size_t)B * H, st));
+    if (s0 == 0) ASR_CHECK_HIP(hipMemsetAsync(dc_ws, 0, sizeof(float) * 2 * (size_t)B * H, st));
     const int vec = (H % 4 == 0) && (((uintptr_t)G & 15) == 0) && (((uintptr_t)W_hhT & 15) == 0);
     dim3 grid(cdiv(H, 16), 2, cdiv(B, 16));
-    for (int step = 0; step < T; ++step) {
+    for (int step = s0; step < s1; ++step) {
         hipLaunchKernelGGL(blstm_bwd_step_kernel, grid, dim3(1024), 0, st, W_hhT, G, Cs, dHout, dho_t,
                            dho_b, lengths, dc_ws, T, B, H, step, vec);
     }
@@ -220,9 +221,11 @@ template <int MT, int KQ4>
 __global__ __launch_bounds__(256) void blstm_fwd_persist_kernel(
     const float *__restrict__ W_hh, float *__restrict__ G, float *__restrict__ Cs,
     float *__restrict__ Hout, int64_t ho_t, int64_t ho_b, const int32_t *__restrict__ lengths, int T,
-    int B, int H, float *hx, unsigned *flags, unsigned *err, int dbg, int tagmode) {
+    int B, int H, int s0, int s1, float *hx, unsigned *flags, unsigned *err, int dbg, int tagmode) {
     __shared__ float red[2][4][MT][16][17];
     __shared__ int s_abort;
+    // latency-bound chain: when GEMM waves of another stream share the SIMD, issue these first
+    __builtin_amdgcn_s_setprio(3);
     const int jt = blockIdx.x, d = blockIdx.y, NJ = gridDim.x;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i = lane & 15, q = lane >> 4;
@@ -242,6 +245,10 @@ __global__ __launch_bounds__(256) void blstm_fwd_persist_kernel(
     const bool valid = owner && bi < B && jo < H;
     const int len = valid ? lengths[bi] : 0;
     float c = 0.f;
+    if (s0 > 0 && valid) {   // continuation launch: the cell state of step s0-1 is in Cs, h_{s0-1} still in hx
+        const int tprev = d == 0 ? s0 - 1 : T - s0;
+        c = Cs[(((int64_t)tprev * B + bi) * 2 + d) * H + jo];
+    }
     const int chunk = MT * 64;                               // floats per workgroup per step
     float *hxd = hx + (int64_t)d * 2 * NJ * chunk;
     __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(hxd, 0, 2 * NJ * chunk * 4, 0x00020000);
@@ -249,7 +256,7 @@ __global__ __launch_bounds__(256) void blstm_fwd_persist_kernel(
     if (tid == 0) s_abort = 0;
     __syncthreads();
 
-    for (int s = 0; s < T; ++s) {
+    for (int s = s0; s < s1; ++s) {
         const int t = d == 0 ? s : T - 1 - s;
         const int64_t grow = (((int64_t)t * B + bi) * 2 + d) * 4 * H;
         float pre[4] = {0.f, 0.f, 0.f, 0.f};
@@ -488,13 +495,15 @@ template <int UW, int NMT>
 __global__ __launch_bounds__(256) void blstm_bwd_rs_kernel(
     const float *__restrict__ W_hh, float *__restrict__ G, const float *__restrict__ Cs,
     const float *__restrict__ dHout, int64_t dho_t, int64_t dho_b, const int32_t *__restrict__ lengths,
-    int T, int B, int H, float *xP, unsigned *flags, unsigned *err, int dbg, int tagmode) {
+    int T, int B, int H, int s0, int s1, float *__restrict__ dc_ws, float *xP, unsigned *flags, unsigned *err,
+    int dbg, int tagmode) {
     constexpr int KL = 4 * UW, KS = KL / 4, DSTR = KL + 4;
     constexpr int NI = 16 * UW / 4;     // 16-byte items per source workgroup (16 rows x UW/4)
     constexpr int NG = 256 / NI;        // thread groups that split the sources
     __shared__ float dgl[16][DSTR];
     __shared__ __attribute__((aligned(16))) float part[NG][NI][4];
     __shared__ int s_abort;
+    __builtin_amdgcn_s_setprio(3);   // see blstm_fwd_persist_kernel
     const int jt = blockIdx.x, d = blockIdx.y, bt = blockIdx.z, NJT = gridDim.x, NBT = gridDim.z;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i = lane & 15, q = lane >> 4;
@@ -520,6 +529,7 @@ __global__ __launch_bounds__(256) void blstm_bwd_rs_kernel(
     const bool valid = owner && b < B && j < H;
     const int len = valid ? lengths[b] : 0;
     float dcarry = 0.f;
+    if (s0 > 0 && valid) dcarry = dc_ws[((int64_t)d * B + b) * H + j];   // continuation launch
     const int64_t slotf = (int64_t)NJT * 16 * Hp;                       // floats per parity slot
     float *xg = xP + ((int64_t)(d * NBT + bt) * 2) * slotf;
     __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(xg, 0, (int)(2 * slotf * 4), 0x00020000);
@@ -527,7 +537,7 @@ __global__ __launch_bounds__(256) void blstm_bwd_rs_kernel(
     if (tid == 0) s_abort = 0;
     __syncthreads();
 
-    for (int s = 0; s < T; ++s) {
+    for (int s = s0; s < s1; ++s) {
         const int t = d == 0 ? T - 1 - s : s;
         const int tp = d == 0 ? t - 1 : t + 1;   // the forward pass's previous time
         const int64_t grow = (((int64_t)t * B + b) * 2 + d) * 4 * H;
@@ -655,6 +665,7 @@ __global__ __launch_bounds__(256) void blstm_bwd_rs_kernel(
                 __hip_atomic_store(fl + jt, (unsigned)(s + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
+    if (s1 < T && valid) dc_ws[((int64_t)d * B + b) * H + j] = dcarry;   // picked up by the next launch
 }
 
 // ------------------------------------------------------------ host dispatch --
@@ -689,11 +700,11 @@ static bool al16p(const void *p) { return (((uintptr_t)p) & 15) == 0; }
 template <int MT>
 static bool launch_fwd_persist(int kq4, dim3 grid, hipStream_t st, const float *W_hh, float *G, float *Cs,
                                float *Hout, int64_t ho_t, int64_t ho_b, const int32_t *lengths, int T, int B,
-                               int H, float *hx, unsigned *flags, unsigned *err) {
+                               int H, int s0, int s1, float *hx, unsigned *flags, unsigned *err) {
 #define FWD_CASE(K)                                                                                       \
     case K:                                                                                               \
         hipLaunchKernelGGL((blstm_fwd_persist_kernel<MT, K>), grid, dim3(256), 0, st, W_hh, G, Cs, Hout,  \
-                           ho_t, ho_b, lengths, T, B, H, hx, flags, err, g_dbg, g_tagmode);               \
+                           ho_t, ho_b, lengths, T, B, H, s0, s1, hx, flags, err, g_dbg, g_tagmode);       \
         return true;
     switch (kq4) {
         FWD_CASE(1) FWD_CASE(2) FWD_CASE(3) FWD_CASE(4) FWD_CASE(5) FWD_CASE(6) FWD_CASE(7) FWD_CASE(8)
@@ -702,38 +713,56 @@ static bool launch_fwd_persist(int kq4, dim3 grid, hipStream_t st, const float *
     return false;
 }
 
-extern "C" int asr_blstm_fwd(const float *W_hh, float *G, float *Cs, float *Hout, int64_t ho_t,
-                             int64_t ho_b, const int32_t *lengths, int T, int B, int H, float *ws,
-                             void *stream) {
+// Steps [s0, s1) of the layer (step s = frame s of the forward direction and frame T-1-s of the
+// reverse direction).  A launch with s0 > 0 continues the previous one on the same ws: the
+// exchange buffer still holds h_{s0-1} with the right epoch tags and c_{s0-1} is read from Cs.
+extern "C" int asr_blstm_fwd_range(const float *W_hh, float *G, float *Cs, float *Hout, int64_t ho_t,
+                                   int64_t ho_b, const int32_t *lengths, int T, int B, int H, int s0, int s1,
+                                   float *ws, void *stream) {
     ASR_CHECK_ARG(W_hh && G && Cs && Hout && lengths, "blstm_fwd: null pointer");
     ASR_CHECK_ARG(T > 0 && B > 0 && H > 0, "blstm_fwd: bad shape T=%d B=%d H=%d", T, B, H);
+    ASR_CHECK_ARG(0 <= s0 && s0 < s1 && s1 <= T, "blstm_fwd: bad step range [%d, %d) of %d", s0, s1, T);
     hipStream_t st = (hipStream_t)stream;
     const int NJ = cdiv(H, 4), MT = cdiv(B, 16);
     const int kq4 = (cdiv(H, 16) + 3) / 4;
     const bool persist = ws != nullptr && H % 4 == 0 && NJ <= 128 && MT <= 2 && kq4 <= 8 && al16p(W_hh) &&
                          al16p(ws);
-    if (!persist) return blstm_fwd_steps(W_hh, G, Cs, Hout, ho_t, ho_b, lengths, T, B, H, stream);
+    if (!persist) return blstm_fwd_steps(W_hh, G, Cs, Hout, ho_t, ho_b, lengths, T, B, H, s0, s1, stream);
     unsigned *flags = reinterpret_cast<unsigned *>(ws);
     unsigned *err = flags + BLSTM_ERR_WORD;
     float *hx = ws + BLSTM_HX_OFF;
-    ASR_CHECK_HIP(hipMemsetAsync(flags, 0, sizeof(unsigned) * BLSTM_FLAG_WORDS, st));
-    if (g_tagmode)   // every exchanged float starts with the "wrong" epoch tag (LSB = 1)
-        ASR_CHECK_HIP(hipMemsetAsync(hx, 0xFF, sizeof(float) * (size_t)4 * NJ * MT * 64, st));
+    if (s0 == 0) {
+        ASR_CHECK_HIP(hipMemsetAsync(flags, 0, sizeof(unsigned) * BLSTM_FLAG_WORDS, st));
+        if (g_tagmode)   // every exchanged float starts with the "wrong" epoch tag (LSB = 1)
+            ASR_CHECK_HIP(hipMemsetAsync(hx, 0xFF, sizeof(float) * (size_t)4 * NJ * MT * 64, st));
+    }
     dim3 grid(NJ, 2);
-    bool ok = MT == 1 ? launch_fwd_persist<1>(kq4, grid, st, W_hh, G, Cs, Hout, ho_t, ho_b, lengths, T, B, H, hx,
-                                              flags, err)
-                      : launch_fwd_persist<2>(kq4, grid, st, W_hh, G, Cs, Hout, ho_t, ho_b, lengths, T, B, H, hx,
-                                              flags, err);
+    bool ok = MT == 1 ? launch_fwd_persist<1>(kq4, grid, st, W_hh, G, Cs, Hout, ho_t, ho_b, lengths, T, B, H, s0,
+                                              s1, hx, flags, err)
+                      : launch_fwd_persist<2>(kq4, grid, st, W_hh, G, Cs, Hout, ho_t, ho_b, lengths, T, B, H, s0,
+                                              s1, hx, flags, err);
     ASR_CHECK_ARG(ok, "blstm_fwd: no persistent instantiation for H=%d", H);
     ASR_CHECK_LAUNCH("blstm_fwd_persist_kernel");
     return ASR_OK;
 }
 
-extern "C" int asr_blstm_bwd(const float *W_hh, const float *W_hhT, float *G, const float *Cs,
-                             const float *dHout, int64_t dho_t, int64_t dho_b, const int32_t *lengths,
-                             float *dc_ws, int T, int B, int H, float *ws, void *stream) {
+extern "C" int asr_blstm_fwd(const float *W_hh, float *G, float *Cs, float *Hout, int64_t ho_t,
+                             int64_t ho_b, const int32_t *lengths, int T, int B, int H, float *ws,
+                             void *stream) {
+    ASR_CHECK_ARG(T > 0, "blstm_fwd: bad shape T=%d B=%d H=%d", T, B, H);
+    return asr_blstm_fwd_range(W_hh, G, Cs, Hout, ho_t, ho_b, lengths, T, B, H, 0, T, ws, stream);
+}
+
+// Steps [s0, s1) of the backward recurrence (step s = frame T-1-s of the forward direction and
+// frame s of the reverse direction); a launch with s0 > 0 continues the previous one on the
+// same ws and dc_ws.
+extern "C" int asr_blstm_bwd_range(const float *W_hh, const float *W_hhT, float *G, const float *Cs,
+                                   const float *dHout, int64_t dho_t, int64_t dho_b, const int32_t *lengths,
+                                   float *dc_ws, int T, int B, int H, int s0, int s1, float *ws, void *stream) {
     ASR_CHECK_ARG(W_hhT && G && Cs && dHout && lengths && dc_ws, "blstm_bwd: null pointer");
     ASR_CHECK_ARG(T > 0 && B > 0 && H > 0, "blstm_bwd: bad shape T=%d B=%d H=%d", T, B, H);
+    ASR_CHECK_ARG(0 <= s0 && s0 < s1 && s1 <= T, "blstm_bwd: bad step range [%d, %d) of %d", s0, s1, T);
+    const bool full = s0 == 0 && s1 == T;
     hipStream_t st = (hipStream_t)stream;
     const int NJT = cdiv(H, 16), NBT = cdiv(B, 16);
     const int kq4 = (cdiv(4 * H, 16) + 3) / 4;
@@ -751,12 +780,14 @@ extern "C" int asr_blstm_bwd(const float *W_hh, const float *W_hhT, float *G, co
             dim3 g2(njt, 2, NBT);
             float *xP = ws + BLSTM_HX_OFF;
             bool launched = true;
-            ASR_CHECK_HIP(hipMemsetAsync(flags, 0, sizeof(unsigned) * BLSTM_FLAG_WORDS, st));
-            if (g_tagmode)
-                ASR_CHECK_HIP(hipMemsetAsync(xP, 0xFF, (size_t)xbytes * 2 * NBT, st));
+            if (s0 == 0) {
+                ASR_CHECK_HIP(hipMemsetAsync(flags, 0, sizeof(unsigned) * BLSTM_FLAG_WORDS, st));
+                if (g_tagmode)
+                    ASR_CHECK_HIP(hipMemsetAsync(xP, 0xFF, (size_t)xbytes * 2 * NBT, st));
+            }
 #define RS_CASE(U, N)                                                                                   \
     hipLaunchKernelGGL((blstm_bwd_rs_kernel<U, N>), g2, dim3(256), 0, st, W_hh, G, Cs, dHout, dho_t,   \
-                       dho_b, lengths, T, B, H, xP, flags, err, g_dbg, g_tagmode)
+                       dho_b, lengths, T, B, H, s0, s1, dc_ws, xP, flags, err, g_dbg, g_tagmode)
             if (uw == 8) {
                 switch (nmt) {
                     case 1: RS_CASE(8, 1); break;
@@ -785,6 +816,7 @@ extern "C" int asr_blstm_bwd(const float *W_hh, const float *W_hhT, float *G, co
         }
     }
     dim3 grid(NJT, 2, NBT);
+    if (!full) persist = false;   // the dG-exchange kernel (A/B timing only) runs whole layers
     if (persist) {
         ASR_CHECK_HIP(hipMemsetAsync(flags, 0, sizeof(unsigned) * BLSTM_FLAG_WORDS, st));
 #define BWD_CASE(K)                                                                                        \
@@ -799,7 +831,15 @@ extern "C" int asr_blstm_bwd(const float *W_hh, const float *W_hhT, float *G, co
         }
 #undef BWD_CASE
     }
-    if (!persist) return blstm_bwd_steps(W_hhT, G, Cs, dHout, dho_t, dho_b, lengths, dc_ws, T, B, H, stream);
+    if (!persist)
+        return blstm_bwd_steps(W_hhT, G, Cs, dHout, dho_t, dho_b, lengths, dc_ws, T, B, H, s0, s1, stream);
     ASR_CHECK_LAUNCH("blstm_bwd_persist_kernel");
     return ASR_OK;
+}
+
+extern "C" int asr_blstm_bwd(const float *W_hh, const float *W_hhT, float *G, const float *Cs,
+                             const float *dHout, int64_t dho_t, int64_t dho_b, const int32_t *lengths,
+                             float *dc_ws, int T, int B, int H, float *ws, void *stream) {
+    ASR_CHECK_ARG(T > 0, "blstm_bwd: bad shape T=%d B=%d H=%d", T, B, H);
+    return asr_blstm_bwd_range(W_hh, W_hhT, G, Cs, dHout, dho_t, dho_b, lengths, dc_ws, T, B, H, 0, T, ws, stream);
 }

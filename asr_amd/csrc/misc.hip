@@ -183,6 +183,32 @@ extern "C" int asr_dropout_fwd(const float *x, float *y, uint8_t *mask, int64_t 
     ASR_CHECK_LAUNCH("dropout_fwd_kernel");
     return ASR_OK;
 }
+__global__ __launch_bounds__(256) void dropout_fwd_block_kernel(const float *__restrict__ x,
+                                                                float *__restrict__ y,
+                                                                uint8_t *__restrict__ mask, int64_t rows,
+                                                                int64_t cols, int64_t ld, int64_t first,
+                                                                uint32_t thresh, float scale, uint64_t seed) {
+    const int64_t n = rows * cols;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (int64_t)gridDim.x * 256) {
+        const int64_t o = (e / cols) * ld + e % cols;
+        const uint8_t keep = mix32(seed + (uint64_t)(first + o) * 0x9E3779B97F4A7C15ULL) >= thresh;
+        mask[o] = keep;
+        y[o] = keep ? x[o] * scale : 0.f;
+    }
+}
+extern "C" int asr_dropout_fwd_block(const float *x, float *y, uint8_t *mask, int64_t rows, int64_t cols,
+                                     int64_t ld, int64_t first, float p, uint64_t seed, void *stream) {
+    ASR_CHECK_ARG(x && y && mask && rows >= 0 && cols >= 0 && ld >= cols && first >= 0 && p >= 0.f && p < 1.f,
+                  "dropout_fwd_block: bad argument");
+    const int64_t n = rows * cols;
+    if (n == 0) return ASR_OK;
+    const uint32_t thresh = (uint32_t)((double)p * 4294967296.0);
+    const int blocks = (int)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256);
+    hipLaunchKernelGGL(dropout_fwd_block_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, y, mask,
+                       rows, cols, ld, first, thresh, 1.0f / (1.0f - p), seed);
+    ASR_CHECK_LAUNCH("dropout_fwd_block_kernel");
+    return ASR_OK;
+}
 extern "C" int asr_dropout_bwd(const float *dy, const uint8_t *mask, float *dx, int64_t n, float p,
                                void *stream) {
     ASR_CHECK_ARG(dy && dx && mask && n >= 0 && p >= 0.f && p < 1.f, "dropout_bwd: bad argument");

@@ -27,6 +27,20 @@ def side_stream(device):
     return s
 
 
+_pipes = {}
+
+
+def pipe_stream(device):
+    """Second helper stream: the chunk-pipelined GEMMs that ARE on the critical path (the main
+    stream joins it at the end of every layer), kept apart from the weight-gradient stream so the
+    two kinds of work never queue behind each other."""
+    s = _pipes.get(device.index)
+    if s is None:
+        s = torch.cuda.Stream(device=device)
+        _pipes[device.index] = s
+    return s
+
+
 def _join(device):
     torch.cuda.current_stream(device).wait_stream(side_stream(device))
     _tls.armed = False

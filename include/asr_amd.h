@@ -133,6 +133,14 @@ int64_t asr_blstm_ws_floats(int B, int H);
 int asr_blstm_fwd(const float *W_hh, float *G, float *Cs, float *Hout,
                   int64_t ho_t, int64_t ho_b, const int32_t *lengths,
                   int T, int B, int H, float *ws, void *stream);
+/* The same recurrence (Models/encoder.py:33), steps [s0, s1) only: step s is frame s of the
+ * forward direction and frame T-1-s of the reverse direction.  s0 = 0 starts a layer; a call
+ * with s0 > 0 continues the previous call on the same G/Cs/Hout/ws (nothing else may use ws
+ * in between).  Lets the host overlap the next layer's input projection of the frames that
+ * are already final with the rest of the recurrence. */
+int asr_blstm_fwd_range(const float *W_hh, float *G, float *Cs, float *Hout,
+                        int64_t ho_t, int64_t ho_b, const int32_t *lengths,
+                        int T, int B, int H, int s0, int s1, float *ws, void *stream);
 
 /* Backward of the recurrence.
  *   W_hh  [2][4H][H]   as in the forward (used by the persistent kernel; may be NULL)
@@ -145,6 +153,13 @@ int asr_blstm_fwd(const float *W_hh, float *G, float *Cs, float *Hout,
 int asr_blstm_bwd(const float *W_hh, const float *W_hhT, float *G, const float *Cs, const float *dHout,
                   int64_t dho_t, int64_t dho_b, const int32_t *lengths,
                   float *dc_ws, int T, int B, int H, float *ws, void *stream);
+/* Steps [s0, s1) of the same backward (autograd of Models/encoder.py:33): step s is frame
+ * T-1-s of the forward direction and frame s of the reverse direction; after the call the
+ * rows of G for those frames hold the final pre-activation gradients.  s0 > 0 continues the
+ * previous call on the same G/dc_ws/ws. */
+int asr_blstm_bwd_range(const float *W_hh, const float *W_hhT, float *G, const float *Cs, const float *dHout,
+                        int64_t dho_t, int64_t dho_b, const int32_t *lengths,
+                        float *dc_ws, int T, int B, int H, int s0, int s1, float *ws, void *stream);
 
 /* inverted dropout between encoder layers (nn.LSTM dropout=, Models/encoder.py:26):
  * y = x * mask / (1-p), mask ~ Bernoulli(1-p) from a counter-based hash of
@@ -153,6 +168,12 @@ int asr_dropout_fwd(const float *x, float *y, uint8_t *mask, int64_t n, float p,
                     uint64_t seed, void *stream);
 int asr_dropout_bwd(const float *dy, const uint8_t *mask, float *dx, int64_t n, float p,
                     void *stream);
+/* The same dropout (Models/encoder.py:26) on a rows x cols block of a larger row-major tensor
+ * with leading dimension ld: x/y/mask point at the block's first element, `first` is that
+ * element's index in the whole tensor, so the block gets exactly the mask asr_dropout_fwd
+ * would give it. */
+int asr_dropout_fwd_block(const float *x, float *y, uint8_t *mask, int64_t rows, int64_t cols, int64_t ld,
+                          int64_t first, float p, uint64_t seed, void *stream);
 
 /* ------------------------------------------------- attention decoder loop --
  * Replaces the L-step teacher-forced loop Models/decoder.py:52-60 with

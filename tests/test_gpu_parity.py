@@ -192,6 +192,50 @@ def test_persistent_and_stepwise_recurrence_agree():
     assert not E.persistent_error_flags()
 
 
+@pytest.mark.parametrize("H,B,T,chunks,p", [(320, 32, 70, 4, 0.0), (320, 32, 131, 3, 0.3), (64, 7, 97, 5, 0.3),
+                                            (10, 5, 66, 4, 0.3), (320, 20, 64, 64, 0.0)])
+def test_chunk_pipelined_encoder_matches_whole_layer_launches(H, B, T, chunks, p):
+    """The chunked recurrence launches (asr_blstm_fwd_range / asr_blstm_bwd_range) with the next
+    layer's projection, the dropout blocks and dX accumulated per chunk on the second stream,
+    against one launch per layer with whole-tensor GEMMs: same dropout masks (same seed), results
+    equal up to the summation order of the split GEMMs.  H=10 takes the step-wise kernels."""
+    from asr_amd.Models import encoder as E
+    from oracle import ref_model as R
+    dev = _dev()
+    hp = R.make_hp(lmfb_dim=24, frame_stacking=1, num_hidden_nodes=H, num_encoder_layer=3, encoder_dropout=p)
+    torch.manual_seed(H + T)
+    enc = E.Encoder(hp).to(dev).train()
+    lengths = torch.linspace(T, max(1, T // 3), B).long()
+    x = torch.randn(B, T, 24)
+    for b in range(B):
+        x[b, lengths[b]:] = 0
+    w = torch.randn(B, T, 2 * H, device=dev)
+    outs = []
+    old = E.PIPE_CHUNKS
+    for nch in (1, chunks):
+        E.PIPE_CHUNKS = nch
+        try:
+            for q in enc.parameters():
+                q.grad = None
+            torch.manual_seed(4242)            # the dropout seed is drawn from torch's generator
+            xd = x.to(dev).requires_grad_(True)
+            h = enc(xd, lengths)
+            (h * w).sum().backward()
+            torch.cuda.synchronize()
+            outs.append((h.detach().cpu(), xd.grad.cpu(), [q.grad.cpu() for q in enc.parameters()]))
+        finally:
+            E.PIPE_CHUNKS = old
+    (h1, dx1, g1), (h2, dx2, g2) = outs
+    assert rel_err(h1, h2) < 1e-5
+    assert rel_err(dx1, dx2) < 2e-5
+    for a, b_ in zip(g1, g2):
+        assert rel_err(a, b_) < 2e-5
+    for b in range(B):
+        if lengths[b] < T:
+            assert float(h2[b, lengths[b]:].abs().max()) == 0.0
+    assert not E.persistent_error_flags()
+
+
 @pytest.mark.parametrize("B,T,He,Hd,V,L,lens", [(3, 17, 8, 8, 11, 5, [17, 9, 4]), (4, 70, 6, 10, 13, 6, [70, 64, 65, 1]),
                                                 (2, 130, 16, 320, 50, 4, [130, 77]), (17, 150, 12, 16, 9, 3, None),
                                                 (3, 40, 5, 9, 7, 4, [40, 22, 7])])
