@@ -220,12 +220,11 @@ __device__ __forceinline__ bool poll_flags(unsigned *flags, int n, unsigned want
 template <int MT, int KQ4>
 __global__ __launch_bounds__(256) void blstm_fwd_persist_kernel(
     const float *__restrict__ W_hh, float *__restrict__ G, float *__restrict__ Cs,
-    float *__restrict__ Hout, int64_t ho_t, int64_t ho_b, const int32_t *__restrict__ lengths, int T,
-    int B, int H, int s0, int s1, float *hx, unsigned *flags, unsigned *err, int dbg, int tagmode) {
+    float *__restrict__ Hout, int64_t ho_t, int64_t ho_b, int64_t hout_bytes,
+    const int32_t *__restrict__ lengths, int T, int B, int H, int s0, int s1, float *hx, unsigned *flags,
+    unsigned *err, int dbg, int tagmode) {
     __shared__ float red[2][4][MT][16][17];
     __shared__ int s_abort;
-    // latency-bound chain: when GEMM waves of another stream share the SIMD, issue these first
-    __builtin_amdgcn_s_setprio(3);
     const int jt = blockIdx.x, d = blockIdx.y, NJ = gridDim.x;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i = lane & 15, q = lane >> 4;
@@ -256,93 +255,56 @@ __global__ __launch_bounds__(256) void blstm_fwd_persist_kernel(
     if (tid == 0) s_abort = 0;
     __syncthreads();
 
-    for (int s = s0; s < s1; ++s) {
-        const int t = d == 0 ? s : T - 1 - s;
-        const int64_t grow = (((int64_t)t * B + bi) * 2 + d) * 4 * H;
-        float pre[4] = {0.f, 0.f, 0.f, 0.f};
-        if (valid) {
+    // Order of the vector-memory instructions inside a step (s_waitcnt vmcnt counts loads AND
+    // stores, in issue order, so whatever is issued before the exchange loads is waited for with
+    // them):  exchange loads of h_{s-1}  ->  this step's input-projection gates (HBM latency,
+    // needed only after the MFMAs)  ->  the PREVIOUS step's saved activations (stores nobody in
+    // the launch waits for)  ->  wait for the exchange loads only.
+    // All of it branch-free (buffer accesses; invalid lanes get an out-of-range offset: loads
+    // return 0, stores are dropped), so the compiler's wait counts are exact on the one path.
+    // The set-up loads are consumed here: a load still pending at the loop entry would cost a
+    // conservative queue drain in EVERY iteration.
 #pragma unroll
-            for (int g = 0; g < 4; ++g) pre[g] = G[grow + g * H + jo];
-        }
-        if (s > 0) {
-            if (!tagmode) {
-                if (wave == 0 && !(dbg & 1)) {
-                    if (!poll_flags(fl, NJ, (unsigned)s)) {
-                        if (lane == 0) {
-                            s_abort = 1;
-                            __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        }
-                    }
-                }
-                __syncthreads();
-                if (s_abort) break;
-            }
-            const int pbase = ((s - 1) & 1) * NJ * chunk;
-            float4 a[MT][KQ4];
-            const unsigned want = (unsigned)(((s - 1) >> 1) & 1);
-            for (int spins = 0;; ++spins) {
-                bool ok = true;
-#pragma unroll
-                for (int m = 0; m < MT; ++m)
-#pragma unroll
-                    for (int f = 0; f < KQ4; ++f) {
-                        // branch-free: an out-of-range offset makes the buffer load return zeros
-                        const int jtk = kb / 4 + f;
-                        const bool in = jtk < NJ;
-                        a[m][f] = ld4_sc1(rsrc, in ? (pbase + jtk * chunk + (m * 16 + i) * 4) * 4 : OOB_OFF);
-                        ok = ok & (tags_ok(a[m][f], want) | !in);
-                    }
-                if (!tagmode || (dbg & 1) || __all(ok)) break;   // wave-uniform
-                if (spins >= SPIN_LIMIT) {
-                    if (lane == 0) {
-                        s_abort = 1;
-                        __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    }
-                    break;
-                }
-                __builtin_amdgcn_s_sleep(1);
-            }
-#pragma unroll
-            for (int m = 0; m < MT; ++m) {
-                f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int f = 0; f < KQ4; ++f) {
-                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m][f].x, wreg[f].x, acc0, 0, 0, 0);
-                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m][f].y, wreg[f].y, acc1, 0, 0, 0);
-                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m][f].z, wreg[f].z, acc0, 0, 0, 0);
-                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m][f].w, wreg[f].w, acc1, 0, 0, 0);
-                }
-#pragma unroll
-                for (int r = 0; r < 4; ++r) red[s & 1][wave][m][q * 4 + r][i] = acc0[r] + acc1[r];
-            }
-            __syncthreads();
-            if (s_abort) break;
-        }
+    for (int f = 0; f < KQ4; ++f) asm volatile("" ::"v"(wreg[f].x), "v"(wreg[f].y), "v"(wreg[f].z), "v"(wreg[f].w));
+    asm volatile("" ::"v"(c), "v"(len));
+    float sv[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};   // ig, fg, gg, og, c, h of the previous step
+    int sv_g = OOB_OFF, sv_c = OOB_OFF, sv_h = OOB_OFF;   // their byte offsets
+    __amdgpu_buffer_rsrc_t rG = __builtin_amdgcn_make_buffer_rsrc(G, 0, (int)((int64_t)T * B * 8 * H * 4), 0x00020000);
+    __amdgpu_buffer_rsrc_t rC = __builtin_amdgcn_make_buffer_rsrc(Cs, 0, (int)((int64_t)T * B * 2 * H * 4), 0x00020000);
+    __amdgpu_buffer_rsrc_t rH = __builtin_amdgcn_make_buffer_rsrc(Hout, 0, (int)hout_bytes, 0x00020000);
+    const int gstep = valid ? H * 4 : 0;
+
+    auto gate_offset = [&](int t) -> int {
+        return valid ? (int)(((((int64_t)t * B + bi) * 2 + d) * 4 * H + jo) * 4) : OOB_OFF;
+    };
+    auto store_saved = [&]() {
+        const int gs = sv_g == OOB_OFF ? 0 : H * 4;
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(sv[0]), rG, sv_g, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(sv[1]), rG, sv_g + gs, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(sv[2]), rG, sv_g + 2 * gs, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(sv[3]), rG, sv_g + 3 * gs, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(sv[4]), rC, sv_c, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(sv[5]), rH, sv_h, 0, 0);
+    };
+    // cell update of the owner lanes, hand-off store, activations kept for the deferred stores
+    auto cell = [&](int s, int t, int growb, float (&pre)[4], bool recur) {
         if (owner) {
             float h = 0.f;
-            if (valid) {
-                float ig = 0.f, fg = 0.f, gg = 0.f, og = 0.f, cn = 0.f;
-                if (t < len) {
-                    if (s > 0) {
-                        const int m = bi >> 4, r = bi & 15;
+            float ig = 0.f, fg = 0.f, gg = 0.f, og = 0.f, cn = 0.f;
+            if (valid && t < len) {
+                if (recur) {
+                    const int m = bi >> 4, r = bi & 15;
 #pragma unroll
-                        for (int g = 0; g < 4; ++g)
-                            pre[g] += (red[s & 1][0][m][r][g * 4 + u] + red[s & 1][1][m][r][g * 4 + u]) +
-                                      (red[s & 1][2][m][r][g * 4 + u] + red[s & 1][3][m][r][g * 4 + u]);
-                    }
-                    ig = sigmoid_f(pre[0]); fg = sigmoid_f(pre[1]);
-                    gg = tanh_f(pre[2]);    og = sigmoid_f(pre[3]);
-                    cn = fg * c + ig * gg;
-                    h = og * tanh_f(cn);
+                    for (int g = 0; g < 4; ++g)
+                        pre[g] += (red[s & 1][0][m][r][g * 4 + u] + red[s & 1][1][m][r][g * 4 + u]) +
+                                  (red[s & 1][2][m][r][g * 4 + u] + red[s & 1][3][m][r][g * 4 + u]);
                 }
-                c = cn;   // padded rows keep a zero state (reverse direction starts from it)
-                G[grow + 0 * H + jo] = ig;
-                G[grow + 1 * H + jo] = fg;
-                G[grow + 2 * H + jo] = gg;
-                G[grow + 3 * H + jo] = og;
-                Cs[(((int64_t)t * B + bi) * 2 + d) * H + jo] = cn;
-                Hout[t * ho_t + bi * ho_b + d * H + jo] = h;
+                ig = sigmoid_f(pre[0]); fg = sigmoid_f(pre[1]);
+                gg = tanh_f(pre[2]);    og = sigmoid_f(pre[3]);
+                cn = fg * c + ig * gg;
+                h = og * tanh_f(cn);
             }
+            c = cn;   // padded rows keep a zero state (the reverse direction starts from it)
             // the 4 units of a batch row sit on 4 adjacent lanes: one 16-byte sc1 store per row
             const float h1 = __shfl_down(h, 1, 64), h2 = __shfl_down(h, 2, 64), h3 = __shfl_down(h, 3, 64);
             if (u == 0 && !(dbg & 8)) {
@@ -353,6 +315,10 @@ __global__ __launch_bounds__(256) void blstm_fwd_persist_kernel(
                 }
                 __builtin_amdgcn_raw_buffer_store_b128(pk, rsrc, (((s & 1) * NJ + jt) * chunk + bi * 4) * 4, 0, 16);
             }
+            sv[0] = ig; sv[1] = fg; sv[2] = gg; sv[3] = og; sv[4] = cn; sv[5] = h;
+            sv_g = growb;
+            sv_c = valid ? (int)(((((int64_t)t * B + bi) * 2 + d) * H + jo) * 4) : OOB_OFF;
+            sv_h = valid ? (int)((t * ho_t + bi * ho_b + d * H + jo) * 4) : OOB_OFF;
         }
         if (!tagmode) {
             if (!(dbg & 2)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -360,7 +326,104 @@ __global__ __launch_bounds__(256) void blstm_fwd_persist_kernel(
             if (tid == 0)
                 __hip_atomic_store(fl + jt, (unsigned)(s + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
+    };
+
+    int s = s0;
+    if (s == 0) {   // first step of the layer: no recurrent term, nothing pending
+        const int t = d == 0 ? 0 : T - 1;
+        const int growb = gate_offset(t);
+        float pre[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+            pre[g] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rG, growb + g * gstep, 0, 0));
+        asm volatile("" ::"v"(pre[0]), "v"(pre[1]), "v"(pre[2]), "v"(pre[3]));
+        cell(0, t, growb, pre, false);
+        s = 1;
     }
+    for (; s < s1; ++s) {
+        const int t = d == 0 ? s : T - 1 - s;
+        const int growb = gate_offset(t);
+        if (!tagmode) {
+            if (wave == 0 && !(dbg & 1)) {
+                if (!poll_flags(fl, NJ, (unsigned)s)) {
+                    if (lane == 0) {
+                        s_abort = 1;
+                        __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                }
+            }
+            __syncthreads();
+            if (s_abort) break;
+        }
+        const int pbase = ((s - 1) & 1) * NJ * chunk;
+        const unsigned want = (unsigned)(((s - 1) >> 1) & 1);
+        float4 a[MT][KQ4];
+        float pre[4];
+        bool ok = true;
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int f = 0; f < KQ4; ++f) {
+                const int jtk = kb / 4 + f;
+                a[m][f] = ld4_sc1(rsrc, jtk < NJ ? (pbase + jtk * chunk + (m * 16 + i) * 4) * 4 : OOB_OFF);
+            }
+        __builtin_amdgcn_sched_barrier(0);   // keep the issue order: loads return in order
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+            pre[g] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rG, growb + g * gstep, 0, 0));
+        store_saved();
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int f = 0; f < KQ4; ++f) ok = ok & (tags_ok(a[m][f], want) | (kb / 4 + f >= NJ));
+        if (tagmode && !(dbg & 1)) {
+            for (int spins = 0; !__all(ok); ++spins) {   // wave-uniform
+                if (spins >= SPIN_LIMIT) {
+                    if (lane == 0) {
+                        s_abort = 1;
+                        __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(1);
+                ok = true;
+#pragma unroll
+                for (int m = 0; m < MT; ++m)
+#pragma unroll
+                    for (int f = 0; f < KQ4; ++f) {
+                        const int jtk = kb / 4 + f;
+                        a[m][f] = ld4_sc1(rsrc, jtk < NJ ? (pbase + jtk * chunk + (m * 16 + i) * 4) * 4 : OOB_OFF);
+                    }
+                __builtin_amdgcn_sched_barrier(0);   // all loads in flight before the first check
+#pragma unroll
+                for (int m = 0; m < MT; ++m)
+#pragma unroll
+                    for (int f = 0; f < KQ4; ++f) ok = ok & (tags_ok(a[m][f], want) | (kb / 4 + f >= NJ));
+            }
+        }
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int f = 0; f < KQ4; ++f) {
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m][f].x, wreg[f].x, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m][f].y, wreg[f].y, acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m][f].z, wreg[f].z, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m][f].w, wreg[f].w, acc1, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) red[s & 1][wave][m][q * 4 + r][i] = acc0[r] + acc1[r];
+        }
+        // every wave consumes its gate loads here (not only the owner lanes): no load is left
+        // pending across the loop's back edge, where the compiler would have to drain the
+        // whole queue before reusing the registers
+        asm volatile("" ::"v"(pre[0]), "v"(pre[1]), "v"(pre[2]), "v"(pre[3]));
+        __syncthreads();
+        if (s_abort) break;
+        cell(s, t, growb, pre, true);
+    }
+    store_saved();   // the last processed step's saved activations
 }
 
 // grid (NJT = H/16, 2, NBT = ceil(B/16)), block 256: workgroup = 16 hidden units x 16 batch
@@ -495,15 +558,14 @@ template <int UW, int NMT>
 __global__ __launch_bounds__(256) void blstm_bwd_rs_kernel(
     const float *__restrict__ W_hh, float *__restrict__ G, const float *__restrict__ Cs,
     const float *__restrict__ dHout, int64_t dho_t, int64_t dho_b, const int32_t *__restrict__ lengths,
-    int T, int B, int H, int s0, int s1, float *__restrict__ dc_ws, float *xP, unsigned *flags, unsigned *err,
-    int dbg, int tagmode) {
+    int64_t dh_bytes, int T, int B, int H, int s0, int s1, float *__restrict__ dc_ws, float *xP, unsigned *flags,
+    unsigned *err, int dbg, int tagmode) {
     constexpr int KL = 4 * UW, KS = KL / 4, DSTR = KL + 4;
     constexpr int NI = 16 * UW / 4;     // 16-byte items per source workgroup (16 rows x UW/4)
     constexpr int NG = 256 / NI;        // thread groups that split the sources
     __shared__ float dgl[16][DSTR];
     __shared__ __attribute__((aligned(16))) float part[NG][NI][4];
     __shared__ int s_abort;
-    __builtin_amdgcn_s_setprio(3);   // see blstm_fwd_persist_kernel
     const int jt = blockIdx.x, d = blockIdx.y, bt = blockIdx.z, NJT = gridDim.x, NBT = gridDim.z;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i = lane & 15, q = lane >> 4;
@@ -537,94 +599,66 @@ __global__ __launch_bounds__(256) void blstm_bwd_rs_kernel(
     if (tid == 0) s_abort = 0;
     __syncthreads();
 
-    for (int s = s0; s < s1; ++s) {
-        const int t = d == 0 ? T - 1 - s : s;
+    // Vector-memory issue order inside a step, as in the forward kernel (s_waitcnt vmcnt counts
+    // loads and stores in issue order): exchange loads of the partial products  ->  this step's
+    // saved activations (HBM latency, needed after the reduction)  ->  the PREVIOUS step's dG
+    // stores (nobody in the launch reads them)  ->  wait for the exchange loads only.  All of it
+    // branch-free through buffer accesses (inactive lanes: out-of-range offset).
+    __amdgpu_buffer_rsrc_t rG = __builtin_amdgcn_make_buffer_rsrc(G, 0, (int)((int64_t)T * B * 8 * H * 4), 0x00020000);
+    __amdgpu_buffer_rsrc_t rC = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(Cs), 0,
+                                                                  (int)((int64_t)T * B * 2 * H * 4), 0x00020000);
+    __amdgpu_buffer_rsrc_t rD = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(dHout), 0, (int)dh_bytes,
+                                                                  0x00020000);
+    float sv[4] = {0.f, 0.f, 0.f, 0.f};   // dG of the previous step, stored one step late
+    int sv_g = OOB_OFF;
+    // the set-up loads are consumed here: a load pending at the loop entry would cost a
+    // conservative queue drain in every iteration
+#pragma unroll
+    for (int mtl = 0; mtl < NMT; ++mtl)
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) asm volatile("" ::"v"(areg[mtl][ks]));
+    asm volatile("" ::"v"(dcarry), "v"(len));
+
+    struct Act { float ig, fg, gg, og, cc, cp, dh; };
+    auto load_act = [&](int t, bool act, int growb) -> Act {
         const int tp = d == 0 ? t - 1 : t + 1;   // the forward pass's previous time
-        const int64_t grow = (((int64_t)t * B + b) * 2 + d) * 4 * H;
-        float ig = 0.f, fg = 0.f, gg = 0.f, og = 0.f, cc = 0.f, cp = 0.f, dh = 0.f;
-        const bool act = valid && t < len;
-        if (act) {
-            ig = G[grow + j]; fg = G[grow + H + j]; gg = G[grow + 2 * H + j]; og = G[grow + 3 * H + j];
-            cc = Cs[(((int64_t)t * B + b) * 2 + d) * H + j];
-            if (tp >= 0 && tp < T) cp = Cs[(((int64_t)tp * B + b) * 2 + d) * H + j];
-            dh = dHout[t * dho_t + b * dho_b + d * H + j];
-        }
-        if (s > 0) {
-            if (!tagmode) {
-                if (wave == 0 && !(dbg & 1)) {
-                    if (!poll_flags(fl, NJT, (unsigned)s)) {
-                        if (lane == 0) {
-                            s_abort = 1;
-                            __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        }
-                    }
-                }
-                __syncthreads();
-                if (s_abort) break;
-            }
-            {   // sum the NJT partial products of the previous step: every thread issues its
-                // share of the 16-byte loads at once (one memory round trip), then a fixed-order
-                // reduction through LDS
-                const int item = tid % NI, grp = tid / NI;
-                const int ib = item / (UW / 4), ih = item % (UW / 4);
-                const int jj = j0 + 4 * ih;                  // first unit of this item
-                const int off0 = (int)((((s - 1) & 1) * slotf + ((int64_t)(jj >> 4) * 16 + ib) * 16 + (jj & 15)) * 4);
-                float4 sum = zero4();
-                {
-                    constexpr int CH = 8;
-                    const unsigned want = (unsigned)(((s - 1) >> 1) & 1);
-                    for (int w0 = grp; w0 < NJT; w0 += NG * CH) {
-                        float4 v[CH];
-                        for (int spins = 0;; ++spins) {
-                            bool ok = true;
-#pragma unroll
-                            for (int c = 0; c < CH; ++c) {
-                                const int w = w0 + c * NG;
-                                const bool in = w < NJT;
-                                v[c] = ld4_sc1(rsrc, in ? off0 + (int)((int64_t)w * MTILES * 256 * 4) : OOB_OFF);
-                                ok = ok & (tags_ok(v[c], want) | !in);
-                            }
-                            if (!tagmode || (dbg & 1) || __all(ok)) break;   // wave-uniform
-                            if (spins >= SPIN_LIMIT) {
-                                if (lane == 0) {
-                                    s_abort = 1;
-                                    __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                                }
-                                break;
-                            }
-                            __builtin_amdgcn_s_sleep(1);
-                        }
-#pragma unroll
-                        for (int c = 0; c < CH; ++c) {
-                            sum.x += v[c].x; sum.y += v[c].y; sum.z += v[c].z; sum.w += v[c].w;
-                        }
-                    }
-                }
-                *reinterpret_cast<float4 *>(&part[grp][item][0]) = sum;
-            }
-            __syncthreads();
-            if (s_abort) break;
-            if (act) {
-                const int item = bi * (UW / 4) + (ju >> 2);
-                float sum = 0.f;
-#pragma unroll
-                for (int gq = 0; gq < NG; ++gq) sum += part[gq][item][ju & 3];
-                dh += sum;
-            }
-        }
+        const int hs = act ? H * 4 : 0;
+        const int cb = act ? (int)(((((int64_t)t * B + b) * 2 + d) * H + j) * 4) : OOB_OFF;
+        const int cpb = (act && tp >= 0 && tp < T) ? (int)(((((int64_t)tp * B + b) * 2 + d) * H + j) * 4) : OOB_OFF;
+        const int db = act ? (int)((t * dho_t + b * dho_b + d * H + j) * 4) : OOB_OFF;
+        Act a;
+        a.ig = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rG, growb, 0, 0));
+        a.fg = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rG, growb + hs, 0, 0));
+        a.gg = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rG, growb + 2 * hs, 0, 0));
+        a.og = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rG, growb + 3 * hs, 0, 0));
+        a.cc = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rC, cb, 0, 0));
+        a.cp = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rC, cpb, 0, 0));
+        a.dh = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rD, db, 0, 0));
+        return a;
+    };
+    auto store_saved = [&]() {
+        const int hs = sv_g == OOB_OFF ? 0 : H * 4;
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(sv[0]), rG, sv_g, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(sv[1]), rG, sv_g + hs, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(sv[2]), rG, sv_g + 2 * hs, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(sv[3]), rG, sv_g + 3 * hs, 0, 0);
+    };
+    // cell backward of the owner lanes (dh already complete), then the partial products of
+    // this workgroup's dG rows and their hand-off
+    auto cell = [&](int s, bool act, int growb, const Act &a, float dh) {
         float d0 = 0.f, d1 = 0.f, d2 = 0.f, d3 = 0.f;
         if (act) {
-            const float tc = tanh_f(cc);
-            const float dc = dcarry + dh * og * (1.f - tc * tc);
-            d0 = dc * gg * ig * (1.f - ig);
-            d1 = dc * cp * fg * (1.f - fg);
-            d2 = dc * ig * (1.f - gg * gg);
-            d3 = dh * tc * og * (1.f - og);
-            dcarry = dc * fg;
+            const float tc = tanh_f(a.cc);
+            const float dc = dcarry + dh * a.og * (1.f - tc * tc);
+            d0 = dc * a.gg * a.ig * (1.f - a.ig);
+            d1 = dc * a.cp * a.fg * (1.f - a.fg);
+            d2 = dc * a.ig * (1.f - a.gg * a.gg);
+            d3 = dh * tc * a.og * (1.f - a.og);
+            dcarry = dc * a.fg;
         }
-        if (valid) {
-            G[grow + j] = d0; G[grow + H + j] = d1; G[grow + 2 * H + j] = d2; G[grow + 3 * H + j] = d3;
-        }
+        sv[0] = d0; sv[1] = d1; sv[2] = d2; sv[3] = d3;
+        sv_g = valid ? (int)((((((int64_t)(d == 0 ? T - 1 - s : s)) * B + b) * 2 + d) * 4 * H + j) * 4) : OOB_OFF;
+        (void)growb;
         if (owner) {
             dgl[bi][ju] = d0; dgl[bi][UW + ju] = d1; dgl[bi][2 * UW + ju] = d2; dgl[bi][3 * UW + ju] = d3;
         }
@@ -644,17 +678,15 @@ __global__ __launch_bounds__(256) void blstm_bwd_rs_kernel(
 #pragma unroll
                 for (int mtl = 0; mtl < NMT; ++mtl) {
                     const int mt = wave + 4 * mtl;
-                    if (mt < MTILES) {
-                        u32x4 pk = {__float_as_uint(acc[mtl][0]), __float_as_uint(acc[mtl][1]),
-                                    __float_as_uint(acc[mtl][2]), __float_as_uint(acc[mtl][3])};
-                        if (tagmode) {
-                            const unsigned e = (unsigned)((s >> 1) & 1);
-                            pk = u32x4{tag_bits(acc[mtl][0], e), tag_bits(acc[mtl][1], e), tag_bits(acc[mtl][2], e),
-                                       tag_bits(acc[mtl][3], e)};
-                        }
-                        const int64_t off = (s & 1) * slotf + (((int64_t)jt * MTILES + mt) * 16 + i) * 16 + 4 * q;
-                        __builtin_amdgcn_raw_buffer_store_b128(pk, rsrc, (int)(off * 4), 0, 16);
+                    u32x4 pk = {__float_as_uint(acc[mtl][0]), __float_as_uint(acc[mtl][1]),
+                                __float_as_uint(acc[mtl][2]), __float_as_uint(acc[mtl][3])};
+                    if (tagmode) {
+                        const unsigned e = (unsigned)((s >> 1) & 1);
+                        pk = u32x4{tag_bits(acc[mtl][0], e), tag_bits(acc[mtl][1], e), tag_bits(acc[mtl][2], e),
+                                   tag_bits(acc[mtl][3], e)};
                     }
+                    const int64_t off = (s & 1) * slotf + (((int64_t)jt * MTILES + mt) * 16 + i) * 16 + 4 * q;
+                    __builtin_amdgcn_raw_buffer_store_b128(pk, rsrc, mt < MTILES ? (int)(off * 4) : OOB_OFF, 0, 16);
                 }
             }
         }
@@ -664,7 +696,118 @@ __global__ __launch_bounds__(256) void blstm_bwd_rs_kernel(
             if (tid == 0)
                 __hip_atomic_store(fl + jt, (unsigned)(s + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
+    };
+    auto gate_offset = [&](int t) -> int {
+        return (valid && t < len) ? (int)(((((int64_t)t * B + b) * 2 + d) * 4 * H + j) * 4) : OOB_OFF;
+    };
+
+    int s = s0;
+    if (s == 0) {   // first step: nothing to receive, nothing pending
+        const int t = d == 0 ? T - 1 : 0;
+        const bool act = valid && t < len;
+        const int growb = gate_offset(t);
+        const Act a = load_act(t, act, growb);
+        asm volatile("" ::"v"(a.ig), "v"(a.fg), "v"(a.gg), "v"(a.og), "v"(a.cc), "v"(a.cp), "v"(a.dh));
+        cell(0, act, growb, a, a.dh);
+        s = 1;
     }
+    // reduction roles: thread -> (16-byte item of this workgroup's 16 x UW block, group of sources)
+    const int item = tid % NI, grp = tid / NI;
+    const int ib = item / (UW / 4), ih = item % (UW / 4);
+    const int jj = j0 + 4 * ih;                  // first unit of this item
+    constexpr int CH = 8;
+    for (; s < s1; ++s) {
+        const int t = d == 0 ? T - 1 - s : s;
+        const bool act = valid && t < len;
+        const int growb = gate_offset(t);
+        if (!tagmode) {
+            if (wave == 0 && !(dbg & 1)) {
+                if (!poll_flags(fl, NJT, (unsigned)s)) {
+                    if (lane == 0) {
+                        s_abort = 1;
+                        __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                }
+            }
+            __syncthreads();
+            if (s_abort) break;
+        }
+        // sum the NJT partial products of the previous step: every thread issues its share of
+        // the 16-byte loads at once (one memory round trip), then a fixed-order reduction
+        // through LDS.  The first CH*NG sources take the fast path below; more (H > 512 with
+        // UW = 8) are swept by the loop after it.
+        const int off0 = (int)((((s - 1) & 1) * slotf + ((int64_t)(jj >> 4) * 16 + ib) * 16 + (jj & 15)) * 4);
+        const unsigned want = (unsigned)(((s - 1) >> 1) & 1);
+        float4 v[CH];
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+            const int w = grp + c * NG;
+            v[c] = ld4_sc1(rsrc, w < NJT ? off0 + (int)((int64_t)w * MTILES * 256 * 4) : OOB_OFF);
+        }
+        __builtin_amdgcn_sched_barrier(0);   // keep the issue order: loads return in order
+        const Act a = load_act(t, act, growb);
+        store_saved();
+        __builtin_amdgcn_sched_barrier(0);
+        bool ok = true;
+#pragma unroll
+        for (int c = 0; c < CH; ++c) ok = ok & (tags_ok(v[c], want) | (grp + c * NG >= NJT));
+        if (tagmode && !(dbg & 1)) {
+            for (int spins = 0; !__all(ok); ++spins) {   // wave-uniform
+                if (spins >= SPIN_LIMIT) {
+                    if (lane == 0) {
+                        s_abort = 1;
+                        __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(1);
+#pragma unroll
+                for (int c = 0; c < CH; ++c) {
+                    const int w = grp + c * NG;
+                    v[c] = ld4_sc1(rsrc, w < NJT ? off0 + (int)((int64_t)w * MTILES * 256 * 4) : OOB_OFF);
+                }
+                __builtin_amdgcn_sched_barrier(0);   // all loads in flight before the first check
+                ok = true;
+#pragma unroll
+                for (int c = 0; c < CH; ++c) ok = ok & (tags_ok(v[c], want) | (grp + c * NG >= NJT));
+            }
+        }
+        float4 sum = zero4();
+#pragma unroll
+        for (int c = 0; c < CH; ++c) { sum.x += v[c].x; sum.y += v[c].y; sum.z += v[c].z; sum.w += v[c].w; }
+        for (int w0 = grp + CH * NG; w0 < NJT; w0 += NG) {   // rare: more than CH*NG sources
+            float4 x = zero4();
+            for (int spins = 0;; ++spins) {
+                x = ld4_sc1(rsrc, off0 + (int)((int64_t)w0 * MTILES * 256 * 4));
+                if (!tagmode || (dbg & 1) || __all(tags_ok(x, want))) break;
+                if (spins >= SPIN_LIMIT) {
+                    if (lane == 0) {
+                        s_abort = 1;
+                        __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(1);
+            }
+            sum.x += x.x; sum.y += x.y; sum.z += x.z; sum.w += x.w;
+        }
+        *reinterpret_cast<float4 *>(&part[grp][item][0]) = sum;
+        // every wave consumes its activation loads here (not only the owner lanes): no load
+        // is left pending across the loop's back edge
+        asm volatile("" ::"v"(a.ig), "v"(a.fg), "v"(a.gg), "v"(a.og), "v"(a.cc), "v"(a.cp), "v"(a.dh));
+        __syncthreads();
+        if (s_abort) break;
+        float dh = a.dh;
+        if (act) {
+            const int it2 = bi * (UW / 4) + (ju >> 2);
+            float ps = 0.f;
+#pragma unroll
+            for (int gq = 0; gq < NG; ++gq) ps += part[gq][it2][ju & 3];
+            dh += ps;
+        }
+        cell(s, act, growb, a, dh);
+    }
+    store_saved();   // the last processed step's dG
     if (s1 < T && valid) dc_ws[((int64_t)d * B + b) * H + j] = dcarry;   // picked up by the next launch
 }
 
@@ -701,10 +844,13 @@ template <int MT>
 static bool launch_fwd_persist(int kq4, dim3 grid, hipStream_t st, const float *W_hh, float *G, float *Cs,
                                float *Hout, int64_t ho_t, int64_t ho_b, const int32_t *lengths, int T, int B,
                                int H, int s0, int s1, float *hx, unsigned *flags, unsigned *err) {
+    // byte extent of Hout as the kernel addresses it (largest element offset + 1)
+    const int64_t hout_bytes = ((int64_t)(T - 1) * ho_t + (int64_t)(B - 1) * ho_b + 2 * H) * 4;
 #define FWD_CASE(K)                                                                                       \
     case K:                                                                                               \
         hipLaunchKernelGGL((blstm_fwd_persist_kernel<MT, K>), grid, dim3(256), 0, st, W_hh, G, Cs, Hout,  \
-                           ho_t, ho_b, lengths, T, B, H, s0, s1, hx, flags, err, g_dbg, g_tagmode);       \
+                           ho_t, ho_b, hout_bytes, lengths, T, B, H, s0, s1, hx, flags, err, g_dbg,       \
+                           g_tagmode);                                                                    \
         return true;
     switch (kq4) {
         FWD_CASE(1) FWD_CASE(2) FWD_CASE(3) FWD_CASE(4) FWD_CASE(5) FWD_CASE(6) FWD_CASE(7) FWD_CASE(8)
@@ -725,8 +871,11 @@ extern "C" int asr_blstm_fwd_range(const float *W_hh, float *G, float *Cs, float
     hipStream_t st = (hipStream_t)stream;
     const int NJ = cdiv(H, 4), MT = cdiv(B, 16);
     const int kq4 = (cdiv(H, 16) + 3) / 4;
+    // the persistent kernel addresses G / Cs / Hout through 32-bit buffer offsets
+    const int64_t big = (int64_t)0x7fff0000;
     const bool persist = ws != nullptr && H % 4 == 0 && NJ <= 128 && MT <= 2 && kq4 <= 8 && al16p(W_hh) &&
-                         al16p(ws);
+                         al16p(ws) && (int64_t)T * B * 8 * H * 4 < big && ho_t >= 0 && ho_b >= 0 &&
+                         ((int64_t)(T - 1) * ho_t + (int64_t)(B - 1) * ho_b + 2 * H) * 4 < big;
     if (!persist) return blstm_fwd_steps(W_hh, G, Cs, Hout, ho_t, ho_b, lengths, T, B, H, s0, s1, stream);
     unsigned *flags = reinterpret_cast<unsigned *>(ws);
     unsigned *err = flags + BLSTM_ERR_WORD;
@@ -776,7 +925,10 @@ extern "C" int asr_blstm_bwd_range(const float *W_hh, const float *W_hhT, float 
         const int uw = bwd_unit_width(B, H);
         const int njt = cdiv(H, uw), nmt = cdiv(cdiv(H, 16), 4);
         const int64_t xbytes = (int64_t)2 * njt * 16 * (cdiv(H, 16) * 16) * 4;
-        if (njt <= 128 && njt * 2 * NBT <= 256 && 2 * NBT * njt <= BLSTM_FLAG_WORDS && xbytes < 0x7fffffff) {
+        // G / Cs / dHout are addressed through 32-bit buffer offsets
+        const int64_t dh_bytes = ((int64_t)(T - 1) * dho_t + (int64_t)(B - 1) * dho_b + 2 * H) * 4;
+        if (njt <= 128 && njt * 2 * NBT <= 256 && 2 * NBT * njt <= BLSTM_FLAG_WORDS && xbytes < 0x7fffffff &&
+            gbytes < (int64_t)0x7fff0000 && dho_t >= 0 && dho_b >= 0 && dh_bytes < (int64_t)0x7fff0000) {
             dim3 g2(njt, 2, NBT);
             float *xP = ws + BLSTM_HX_OFF;
             bool launched = true;
@@ -787,7 +939,7 @@ extern "C" int asr_blstm_bwd_range(const float *W_hh, const float *W_hhT, float 
             }
 #define RS_CASE(U, N)                                                                                   \
     hipLaunchKernelGGL((blstm_bwd_rs_kernel<U, N>), g2, dim3(256), 0, st, W_hh, G, Cs, dHout, dho_t,   \
-                       dho_b, lengths, T, B, H, s0, s1, dc_ws, xP, flags, err, g_dbg, g_tagmode)
+                       dho_b, lengths, dh_bytes, T, B, H, s0, s1, dc_ws, xP, flags, err, g_dbg, g_tagmode)
             if (uw == 8) {
                 switch (nmt) {
                     case 1: RS_CASE(8, 1); break;
