@@ -250,6 +250,9 @@ def main():
     # full optimiser step (clip + Adam, train.py:60-63), reported beside the metric
     full_ms = None
     if rank == 0 or world > 1:
+        step()                                   # untimed: optimiser state + first-use kernel loads
+        torch.nn.utils.clip_grad_norm_(model.parameters(), hp.clip)
+        opt.step()
         barrier()
         t0 = time.perf_counter()
         for _ in range(max(2, args.steps // 2)):
