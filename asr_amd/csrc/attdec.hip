@@ -824,54 +824,108 @@ extern "C" int asr_attdec_greedy(const asr_attdec_fwd_args *a, const float *W_sy
 // inside (the tanh is recomputed; no read-modify-write of dPH per step), and
 // the conv-filter gradient as a correlation of dF_s with alpha_{s-1}.
 
-// grid (ceil(Hd/16), ceil(B/16)), block 1024
+// grid (ceil(Hd/16), ceil(B/16)), block 1024; dynamic LDS: 16*A floats when lds_sum != 0
 __global__ __launch_bounds__(1024) void dscell_kernel(
     int s, int L, const float *__restrict__ drec_n, const float *__restrict__ dyp_n,
     const float *__restrict__ dsp_part, int64_t part_stride, float *__restrict__ dsp_n,
     const float *__restrict__ W_ssT, const float *__restrict__ W_syT, const float *__restrict__ W_seT,
     const float *__restrict__ gates_s, const float *__restrict__ C_s, const float *__restrict__ C_n,
     const int32_t *__restrict__ lengths, float *__restrict__ dC, float *__restrict__ drec_s, int B, int Hd,
-    int T, int vec) {
+    int T, int vec, int lds_sum) {
     __shared__ float red[T16_MAXW][16][17];
+    extern __shared__ __attribute__((aligned(16))) float dsps[];   // [16][A]: summed dsp partials
     const int lane = threadIdx.x & 63, i = lane & 15;
     const int j0 = blockIdx.x * 16, b0 = blockIdx.y * 16;
     const int A = 2 * Hd;
     const bool has_next = s + 1 < L;
+    const int tid = threadIdx.x;
+    // operands of the cell backward: fetched first, their latency hides under the products
+    const int ebi = tid >> 4, eji = tid & 15;
+    const int eb = b0 + ebi, ej = j0 + eji;
+    const bool ev = tid < 256 && eb < B && ej < Hd;
+    float ig = 0.f, fg = 0.f, gg = 0.f, og = 0.f, cn = 0.f, cp = 0.f, dCv = 0.f;
+    if (ev) {
+        const float *gd = gates_s + (int64_t)eb * 4 * Hd;
+        ig = gd[ej]; fg = gd[Hd + ej]; gg = gd[2 * Hd + ej]; og = gd[3 * Hd + ej];
+        cn = C_n[(int64_t)eb * Hd + ej]; cp = C_s[(int64_t)eb * Hd + ej];
+        dCv = dC[(int64_t)eb * Hd + ej];
+    }
     if (has_next) {
         const int b = b0 + i, j = j0 + i;
         const bool bv = b < B, jv = j < Hd;
+        const int ntile = (T + TT - 1) / TT;
+        if (lds_sum) {
+            // the attention-state gradient arrives as one partial per frame tile: sum them
+            // once per workgroup, every thread's loads in flight together, into LDS
+            const int A4 = A / 4;
+            for (int it = tid; it < 16 * A4; it += 1024) {
+                const int r = it / A4, c4 = it % A4;
+                const int bb = b0 + r;
+                const int np = bb < B ? max(1, (min(lengths[bb], T) + TT - 1) / TT) : 0;
+                const float *src = dsp_part + (int64_t)min(bb, B - 1) * A + c4 * 4;
+                float4 acc = zero4();
+                for (int p0 = 0; p0 < ntile; p0 += 8) {
+                    float4 t[8];
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) {
+                        const bool ok = p0 + c < np;
+                        t[c] = ld4(ok ? src + (int64_t)(p0 + c) * part_stride : W_seT);
+                        if (!ok) t[c] = zero4();
+                    }
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) { acc.x += t[c].x; acc.y += t[c].y; acc.z += t[c].z; acc.w += t[c].w; }
+                }
+                *reinterpret_cast<float4 *>(dsps + r * A + c4 * 4) = acc;
+                if (blockIdx.x == 0 && bb < B) *reinterpret_cast<float4 *>(dsp_n + (int64_t)bb * A + c4 * 4) = acc;
+            }
+        }
         Tile16Acc acc;
         tile16_init(acc);
         tile16_seg(acc, bv ? drec_n + (int64_t)b * 4 * Hd : nullptr, jv ? W_ssT + (int64_t)j * 4 * Hd : nullptr,
                    4 * Hd, vec != 0, W_ssT);
         tile16_seg(acc, bv ? dyp_n + (int64_t)b * Hd : nullptr, jv ? W_syT + (int64_t)j * Hd : nullptr, Hd,
                    vec != 0, W_syT);
-        int nparts = 1;
-        if (bv) nparts = max(1, (min(lengths[b], T) + TT - 1) / TT);
-        tile16_seg(acc, bv ? dsp_part + (int64_t)b * A : nullptr, jv ? W_seT + (int64_t)j * A : nullptr, A,
-                   vec != 0, W_seT, true, nparts, part_stride,
-                   (blockIdx.x == 0 && bv) ? dsp_n + (int64_t)b * A : nullptr, (T + TT - 1) / TT);
+        if (lds_sum) {
+            __syncthreads();
+            // same k-slot split as tile16_seg, A operand from LDS
+            const int wave = tid >> 6, q = lane >> 4;
+            const int slots = (blockDim.x >> 6) * 4;
+            int kq = (A + slots - 1) / slots;
+            kq = (kq + 3) & ~3;
+            const int kb = (wave * 4 + q) * kq;
+            const int ke = min(A, kb + kq);
+            const float *wrow = jv ? W_seT + (int64_t)j * A : nullptr;
+#pragma unroll 4
+            for (int u0 = 0; u0 < kq; u0 += 4) {
+                const int k = kb + u0;
+                float4 a = zero4();
+                if (k < ke) a = *reinterpret_cast<const float4 *>(dsps + i * A + k);
+                const float4 bq = t16_load_fast(wrow, k, ke, W_seT);
+                acc.a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, bq.x, acc.a0, 0, 0, 0);
+                acc.a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, bq.y, acc.a1, 0, 0, 0);
+                acc.a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, bq.z, acc.a0, 0, 0, 0);
+                acc.a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, bq.w, acc.a1, 0, 0, 0);
+            }
+        } else {
+            int nparts = 1;
+            if (bv) nparts = max(1, (min(lengths[b], T) + TT - 1) / TT);
+            tile16_seg(acc, bv ? dsp_part + (int64_t)b * A : nullptr, jv ? W_seT + (int64_t)j * A : nullptr, A,
+                       vec != 0, W_seT, true, nparts, part_stride,
+                       (blockIdx.x == 0 && bv) ? dsp_n + (int64_t)b * A : nullptr, ntile);
+        }
         tile16_reduce(acc, red);
     }
-    const int tid = threadIdx.x;
-    if (tid < 256) {
-        const int bi = tid >> 4, ji = tid & 15;
-        const int b = b0 + bi, j = j0 + ji;
-        if (b < B && j < Hd) {
-            const float dS = has_next ? tile16_get(red, bi, ji) : 0.f;
-            const float *gd = gates_s + (int64_t)b * 4 * Hd;
-            const float ig = gd[j], fg = gd[Hd + j], gg = gd[2 * Hd + j], og = gd[3 * Hd + j];
-            const float cn = C_n[(int64_t)b * Hd + j], cp = C_s[(int64_t)b * Hd + j];
-            const float tc = tanh_f(cn);
-            const float dO = dS * tc;
-            const float dc = dS * og * (1.f - tc * tc) + dC[(int64_t)b * Hd + j];
-            float *dr = drec_s + (int64_t)b * 4 * Hd;
-            dr[j] = dc * gg * ig * (1.f - ig);
-            dr[Hd + j] = dc * cp * fg * (1.f - fg);
-            dr[2 * Hd + j] = dc * ig * (1.f - gg * gg);
-            dr[3 * Hd + j] = dO * og * (1.f - og);
-            dC[(int64_t)b * Hd + j] = dc * fg;
-        }
+    if (ev) {
+        const float dS = has_next ? tile16_get(red, ebi, eji) : 0.f;
+        const float tc = tanh_f(cn);
+        const float dO = dS * tc;
+        const float dc = dS * og * (1.f - tc * tc) + dCv;
+        float *dr = drec_s + (int64_t)eb * 4 * Hd;
+        dr[ej] = dc * gg * ig * (1.f - ig);
+        dr[Hd + ej] = dc * cp * fg * (1.f - fg);
+        dr[2 * Hd + ej] = dc * ig * (1.f - gg * gg);
+        dr[3 * Hd + ej] = dO * og * (1.f - og);
+        dC[(int64_t)eb * Hd + ej] = dc * fg;
     }
 }
 
@@ -929,13 +983,56 @@ __global__ __launch_bounds__(256) void dalpha_kernel(const float *__restrict__ h
     }
     __syncthreads();
     const float *hb = hbatch + (int64_t)b * T * E;
+    const int E4 = E / 4;
+    if (vec && E4 <= 192) {
+        // 4 frames per round: all their hbatch loads (<= 12 x 16 B per lane) are in flight
+        // before the first dot product -- one memory round trip per round, not one per frame
+        float4 dv[3];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const int e4 = lane + 64 * r;
+            dv[r] = e4 < E4 ? *reinterpret_cast<const float4 *>(dgs + e4 * 4) : zero4();
+        }
+        for (int r0 = 0; r0 < DA_TT / 4; r0 += 4) {
+            if (t0 + wave + 4 * r0 >= len) break;   // wave-uniform
+            float4 hv[4][3];
+#pragma unroll
+            for (int uu = 0; uu < 4; ++uu) {
+                const int t = t0 + wave + 4 * (r0 + uu);
+                const float *hr = hb + (int64_t)min(t, len - 1) * E;   // clamped: always a valid row
+#pragma unroll
+                for (int r = 0; r < 3; ++r) hv[uu][r] = ld4(hr + min(lane + 64 * r, E4 - 1) * 4);
+            }
+#pragma unroll
+            for (int uu = 0; uu < 4; ++uu) {
+                const int tt = wave + 4 * (r0 + uu);
+                const int t = t0 + tt;
+                float acc = 0.f;
+#pragma unroll
+                for (int r = 0; r < 3; ++r)   // dv is zero where lane + 64 r is past the row
+                    acc += hv[uu][r].x * dv[r].x + hv[uu][r].y * dv[r].y + hv[uu][r].z * dv[r].z +
+                           hv[uu][r].w * dv[r].w;
+                if (dF_next) {
+                    // frame of dF touched by tap k: t + PADW - k  ->  window row tt + (KW-1) - k
+                    for (int k = lane; k < KW; k += 64) {
+                        const float *fr = dFw + (tt + (KW - 1) - k) * 11;
+#pragma unroll
+                        for (int c = 0; c < NCH; ++c) acc += fr[c] * cws[c * KW + k];
+                    }
+                }
+                acc = wave_sum(acc);
+                if (lane == 0 && t < len) dalpha[(int64_t)b * T + t] = acc;
+            }
+        }
+        return;
+    }
     for (int tt = wave; tt < DA_TT; tt += 4) {
         const int t = t0 + tt;
         if (t >= len) break;  // wave-uniform
         float acc = 0.f;
         if (vec) {
             const float *hr = hb + (int64_t)t * E;
-            for (int e4 = lane; e4 < E / 4; e4 += 64) {
+            for (int e4 = lane; e4 < E4; e4 += 64) {
                 const float4 h = ld4(hr + e4 * 4);
                 const float4 d = *reinterpret_cast<const float4 *>(dgs + e4 * 4);
                 acc += h.x * d.x + h.y * d.y + h.z * d.z + h.w * d.w;
@@ -1264,15 +1361,18 @@ extern "C" int asr_attdec_bwd(const asr_attdec_bwd_args *a, void *stream) {
     if (use_v2)
         hipLaunchKernelGGL(e2_prep_kernel, dim3(cdiv((int64_t)A16p * 12, 256)), dim3(256), 0, st, f->w_ee, f->W_fe,
                            A, A16p, tab);
+    // dscell sums the per-tile dsp partials into LDS (16 rows x A) when that fits beside its tile buffer
+    const size_t ds_smem = sizeof(float) * 16 * (size_t)A;
+    const int ds_lds = (vecT && A % 4 == 0 && ds_smem <= 44 * 1024) ? 1 : 0;
     for (int s = L - 1; s >= 0; --s) {
         const bool has_next = s + 1 < L;
-        hipLaunchKernelGGL(dscell_kernel, dim3(cdiv(Hd, 16), cdiv(B, 16)), dim3(1024), 0, st, s, L,
+        hipLaunchKernelGGL(dscell_kernel, dim3(cdiv(Hd, 16), cdiv(B, 16)), dim3(1024), ds_lds ? ds_smem : 0, st, s, L,
                            has_next ? a->drec + (s + 1) * 4 * BH : (const float *)nullptr,
                            has_next ? a->dyp + (s + 1) * BH : (const float *)nullptr,
                            (const float *)dsp_part, (int64_t)BA,
                            has_next ? a->dsp + (s + 1) * BA : (float *)nullptr, a->W_ssT, a->W_syT, a->W_seT,
                            f->gates + s * 4 * BH, f->C + s * BH, f->C + (s + 1) * BH, f->lengths, dC,
-                           a->drec + s * 4 * BH, B, Hd, T, vecT);
+                           a->drec + s * 4 * BH, B, Hd, T, vecT, ds_lds);
         hipLaunchKernelGGL(dg_kernel, dim3(cdiv(E, 16), cdiv(B, 16)), dim3(1024), 0, st,
                            (const float *)(a->drec + s * 4 * BH), a->dyp + s * BH, a->W_gsT, a->W_gyT,
                            a->dg + s * BE, B, Hd, E, vecT);
