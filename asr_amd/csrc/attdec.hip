@@ -1234,6 +1234,151 @@ __global__ __launch_bounds__(256) void phase2_kernel(
     }
 }
 
+// The same pass on the matrix cores (A % 16 == 0).  grid (ceil(T/64), B, ceil(A/64)), block 256:
+// wave w owns frames [16w, 16w+16) of the 64-frame tile and P3_NAT 16-column tiles of attention
+// units, all L steps with the accumulators in registers.  Per step and column tile:
+//   x[f][a]   = PH + sproj + sum_c F[f][c] W_fe[a][c]     3 x v_mfma_f32_16x16x4 (c padded to 12)
+//   dpre[f][a] = de[f] w_ee[a] (1 - tanh^2 x)              VALU, C/D layout: lane = (a, 4 frames)
+//   dW_fe^T[c][a] += sum_f F[f][c] dpre[f][a]              4 x MFMA, the lane's own dpre as B operand
+// (the sum over f may visit the 16 frames in any order: k-step r takes frame 4*(lane>>4)+r,
+// which is exactly what the lane holds in the C/D layout -- no transpose).
+#define P3_NAT 2
+__global__ __launch_bounds__(256) void phase2_mfma_kernel(
+    const float *__restrict__ PH, const float *__restrict__ sproj /* (L,B,A) */,
+    const float *__restrict__ de /* (L,B,T) */, const float *__restrict__ Fc /* (L,B,T,NCH) */,
+    const float *__restrict__ w_ee, const float *__restrict__ W_fe, const int32_t *__restrict__ lengths,
+    float *__restrict__ dPH, float *__restrict__ part /* [tile*B + b][A][11] */, int L, int B, int T, int A) {
+    __shared__ float fe_s[4][P3_NAT][16][17];
+    __shared__ float ee_s[4][P3_NAT][16];
+    const int b = blockIdx.y, t0 = blockIdx.x * 64;
+    const int len = min(lengths[b], T);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int col = lane & 15, q = lane >> 4;
+    const int a_base = blockIdx.z * (16 * P3_NAT);
+    const int tf = t0 + 16 * wave;
+    float *pout = part + ((int64_t)blockIdx.x * B + b) * A * 11;
+    if (t0 >= len) {   // block-uniform: nothing valid in this tile
+        for (int i = tid; i < 64 * 16 * P3_NAT; i += 256) {
+            const int t = t0 + i / (16 * P3_NAT), a = a_base + i % (16 * P3_NAT);
+            if (t < T && a < A) dPH[((int64_t)b * T + t) * A + a] = 0.f;
+        }
+        for (int i = tid; i < 16 * P3_NAT * 11; i += 256) {
+            const int a = a_base + i / 11;
+            if (a < A) pout[a * 11 + i % 11] = 0.f;
+        }
+        return;
+    }
+    float wee[P3_NAT], wfe[P3_NAT][3], ph[P3_NAT][4];
+    bool av[P3_NAT];
+#pragma unroll
+    for (int n = 0; n < P3_NAT; ++n) {
+        const int a = a_base + 16 * n + col;
+        av[n] = a < A;
+        wee[n] = av[n] ? w_ee[a] : 0.f;
+#pragma unroll
+        for (int ks = 0; ks < 3; ++ks) {
+            const int c = 4 * ks + q;
+            wfe[n][ks] = (av[n] && c < NCH) ? W_fe[a * NCH + c] : 0.f;
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int t = tf + 4 * q + r;
+            ph[n][r] = (av[n] && t < len) ? PH[((int64_t)b * T + t) * A + a] : 0.f;
+        }
+    }
+    // per-step inputs; every load is branch-free (clamped address, value masked)
+    struct In { float dev[4], fa[3], ff[4], sp[P3_NAT]; };
+    const int tA = min(tf + col, len - 1);
+    const bool tAv = tf + col < len;
+    int tq[4];
+    bool tqv[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { tqv[r] = tf + 4 * q + r < len; tq[r] = min(tf + 4 * q + r, len - 1); }
+    auto load_in = [&](int s) -> In {
+        In in;
+        const int64_t sb = (int64_t)s * B + b;
+        const float *dep = de + sb * T;
+        const float *fp = Fc + sb * T * NCH;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float v = dep[tq[r]];
+            in.dev[r] = tqv[r] ? v : 0.f;
+            const float f = fp[(int64_t)tq[r] * NCH + min(col, NCH - 1)];
+            in.ff[r] = (tqv[r] && col < NCH) ? f : 0.f;
+        }
+#pragma unroll
+        for (int ks = 0; ks < 3; ++ks) {
+            const int c = 4 * ks + q;
+            const float f = fp[(int64_t)tA * NCH + min(c, NCH - 1)];
+            in.fa[ks] = (tAv && c < NCH) ? f : 0.f;
+        }
+        const float *spp = sproj + sb * A;
+#pragma unroll
+        for (int n = 0; n < P3_NAT; ++n) {
+            const float v = spp[min(a_base + 16 * n + col, A - 1)];
+            in.sp[n] = av[n] ? v : 0.f;
+        }
+        return in;
+    };
+    float acc_ph[P3_NAT][4], acc_ee[P3_NAT];
+    f32x4 acc_fe[P3_NAT];
+#pragma unroll
+    for (int n = 0; n < P3_NAT; ++n) {
+        acc_ee[n] = 0.f;
+        acc_fe[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc_ph[n][r] = 0.f;
+    }
+    In cur = load_in(0);
+    for (int s = 0; s < L; ++s) {
+        const In nxt = load_in(min(s + 1, L - 1));   // next step's inputs in flight under this step's math
+#pragma unroll
+        for (int n = 0; n < P3_NAT; ++n) {
+            f32x4 x = {ph[n][0] + cur.sp[n], ph[n][1] + cur.sp[n], ph[n][2] + cur.sp[n], ph[n][3] + cur.sp[n]};
+#pragma unroll
+            for (int ks = 0; ks < 3; ++ks) x = __builtin_amdgcn_mfma_f32_16x16x4f32(cur.fa[ks], wfe[n][ks], x, 0, 0, 0);
+            float dp[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float th = tanh_f(x[r]);
+                dp[r] = cur.dev[r] * (1.f - th * th) * wee[n];
+                acc_ph[n][r] += dp[r];
+                acc_ee[n] += cur.dev[r] * th;
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                acc_fe[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(cur.ff[r], dp[r], acc_fe[n], 0, 0, 0);
+        }
+        cur = nxt;
+    }
+#pragma unroll
+    for (int n = 0; n < P3_NAT; ++n) {
+        const int a = a_base + 16 * n + col;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int t = tf + 4 * q + r;
+            if (av[n] && t < T) dPH[((int64_t)b * T + t) * A + a] = acc_ph[n][r];
+        }
+        float e = acc_ee[n];
+        e += __shfl_xor(e, 16, 64);
+        e += __shfl_xor(e, 32, 64);
+        if (q == 0) ee_s[wave][n][col] = e;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) fe_s[wave][n][4 * q + r][col] = acc_fe[n][r];   // [c][a]
+    }
+    __syncthreads();
+    for (int i = tid; i < 16 * P3_NAT * 11; i += 256) {
+        const int al = i / 11, k = i % 11;          // local column, 0 = w_ee slot, 1 + c = W_fe slot
+        const int n = al >> 4, cl = al & 15;
+        const int a = a_base + al;
+        if (a >= A) continue;
+        float v;
+        if (k == 0) v = (ee_s[0][n][cl] + ee_s[1][n][cl]) + (ee_s[2][n][cl] + ee_s[3][n][cl]);
+        else v = (fe_s[0][n][k - 1][cl] + fe_s[1][n][k - 1][cl]) + (fe_s[2][n][k - 1][cl] + fe_s[3][n][k - 1][cl]);
+        pout[a * 11 + k] = v;
+    }
+}
+
 // out[i] = sum_p part[p*n + i]
 __global__ __launch_bounds__(256) void reduce_parts_kernel(const float *__restrict__ part, int nparts,
                                                            int64_t n, float *__restrict__ out) {
@@ -1404,9 +1549,14 @@ extern "C" int asr_attdec_bwd(const asr_attdec_bwd_args *a, void *stream) {
     {
         float *part = post;
         float *sum11 = post + nt * BA * 11;
-        hipLaunchKernelGGL(phase2_kernel, dim3(nt, B, cdiv(A, P2_A)), dim3(256), 0, st, f->PH,
-                           (const float *)f->sproj, (const float *)a->de, (const float *)f->Fc, f->w_ee,
-                           f->W_fe, f->lengths, a->dPH, part, L, B, T, A);
+        if (A % 16 == 0)
+            hipLaunchKernelGGL(phase2_mfma_kernel, dim3(nt, B, cdiv(A, 16 * P3_NAT)), dim3(256), 0, st, f->PH,
+                               (const float *)f->sproj, (const float *)a->de, (const float *)f->Fc, f->w_ee,
+                               f->W_fe, f->lengths, a->dPH, part, L, B, T, A);
+        else
+            hipLaunchKernelGGL(phase2_kernel, dim3(nt, B, cdiv(A, P2_A)), dim3(256), 0, st, f->PH,
+                               (const float *)f->sproj, (const float *)a->de, (const float *)f->Fc, f->w_ee,
+                               f->W_fe, f->lengths, a->dPH, part, L, B, T, A);
         // deterministic two-stage column sum over the (tile, b) partials
         ASR_CHECK(asr_colsum(part, (int)(nt * B), A * 11, (int64_t)A * 11, 0, 0, sum11, 0,
                              sum11 + A * 11 + 64, stream));

@@ -17,7 +17,11 @@
 
 #include "common.cuh"
 
-#define GPAD 4
+// LDS row padding: the k-contiguous source (mode 0) is scattered into the k-major tile as
+// 4-byte writes, lane -> (row = lane/4, k-chunk = lane%4); a row stride = 2 mod 8 floats puts the
+// four k-chunks of a half-wave 8 banks apart (conflict-free); the row-contiguous source (mode 1)
+// writes 16-byte vectors and needs a stride that is a multiple of 4 floats.
+#define GPAD(MODE) ((MODE) == 0 ? 2 : 4)
 
 struct OperandView {
     const float *p;
@@ -123,7 +127,7 @@ struct TileLoader {
 };
 
 template <int R, int GK, int MODE>
-__device__ __forceinline__ void store_tile(float (*lds)[R + GPAD], const float4 (&regs)[R * GK / 1024]) {
+__device__ __forceinline__ void store_tile(float (*lds)[R + GPAD(MODE)], const float4 (&regs)[R * GK / 1024]) {
     const int tid = threadIdx.x;
 #pragma unroll
     for (int i = 0; i < R * GK / 1024; ++i) {
@@ -144,8 +148,8 @@ __device__ __forceinline__ void store_tile(float (*lds)[R + GPAD], const float4 
 template <int BM, int BN, int GK, int AMODE, int BMODE, bool FAST>
 __global__ __launch_bounds__(256) void sgemm_kernel(asr_gemm_desc d, int vecA, int vecB, int ktiles_per_split) {
     constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
-    __shared__ __attribute__((aligned(16))) float As[2][GK][BM + GPAD];
-    __shared__ __attribute__((aligned(16))) float Bs[2][GK][BN + GPAD];
+    __shared__ __attribute__((aligned(16))) float As[2][GK][BM + GPAD(AMODE)];
+    __shared__ __attribute__((aligned(16))) float Bs[2][GK][BN + GPAD(BMODE)];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
