@@ -215,32 +215,41 @@ __device__ __forceinline__ bool poll_flags(unsigned *flags, int n, unsigned want
     return false;
 }
 
-// grid (NJ = H/4, 2), block 256.  Workgroup = 4 hidden units (16 gate columns) of one
-// direction for all MT*16 batch rows.  hx[dir][parity][NJ][MT*16][4]: the h exchange.
-template <int MT, int KQ4>
+// grid (NJ = H/(4 NT), 2, NBT), block 256.  Workgroup = 4*NT hidden units (NT 16-column gate
+// tiles) of one direction for MT*16 batch rows; hx[dir][bt][parity][NJ][MT*16][4 NT]: the h
+// exchange.  (MT, NT) = (1, 2) for 17..32 rows: two batch tiles on separate workgroups, each
+// loading only ITS 16 rows of h_{t-1} per step (20 KB instead of 40 KB at H = 320 -- the price of
+// an in-launch hand-off sits in the consumer CU's memory queue); (2, 1) when H % 8 != 0; (1, 1)
+// for up to 16 rows.
+template <int MT, int NT, int KQ4>
 __global__ __launch_bounds__(256) void blstm_fwd_persist_kernel(
     const float *__restrict__ W_hh, float *__restrict__ G, float *__restrict__ Cs,
     float *__restrict__ Hout, int64_t ho_t, int64_t ho_b, int64_t hout_bytes,
     const int32_t *__restrict__ lengths, int T, int B, int H, int s0, int s1, float *hx, unsigned *flags,
     unsigned *err, int dbg, int tagmode) {
-    __shared__ float red[2][4][MT][16][17];
+    static_assert(MT * NT == 2 || (MT == 1 && NT == 1), "128 (64) owner threads");
+    constexpr int UN = 4 * NT;                               // hidden units per workgroup
+    __shared__ float red[2][4][MT][NT][16][17];
     __shared__ int s_abort;
-    const int jt = blockIdx.x, d = blockIdx.y, NJ = gridDim.x;
+    const int jt = blockIdx.x, d = blockIdx.y, bt = blockIdx.z, NJ = gridDim.x, NBT = gridDim.z;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i = lane & 15, q = lane >> 4;
     constexpr int KQ = KQ4 * 4;
     const int kb = (wave * 4 + q) * KQ;
+    const int b0 = bt * MT * 16;
 
-    float4 wreg[KQ4];
-    {
-        const int gate = i >> 2, j = jt * 4 + (i & 3);
+    float4 wreg[NT][KQ4];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int gate = i >> 2, j = jt * UN + 4 * nt + (i & 3);
         const float *wrow = W_hh + ((int64_t)d * 4 * H + gate * H + j) * H;
 #pragma unroll
-        for (int f = 0; f < KQ4; ++f) wreg[f] = (j < H && kb + 4 * f < H) ? ld4(wrow + kb + 4 * f) : zero4();
+        for (int f = 0; f < KQ4; ++f) wreg[nt][f] = (j < H && kb + 4 * f < H) ? ld4(wrow + kb + 4 * f) : zero4();
     }
-    const bool owner = tid < MT * 64;
-    const int bi = tid >> 2, u = tid & 3;
-    const int jo = jt * 4 + u;
+    const bool owner = tid < MT * NT * 64;
+    const int bl = tid / UN, u = tid % UN;                   // local batch row, local unit
+    const int bi = b0 + bl;
+    const int jo = jt * UN + u;
     const bool valid = owner && bi < B && jo < H;
     const int len = valid ? lengths[bi] : 0;
     float c = 0.f;
@@ -248,10 +257,10 @@ __global__ __launch_bounds__(256) void blstm_fwd_persist_kernel(
         const int tprev = d == 0 ? s0 - 1 : T - s0;
         c = Cs[(((int64_t)tprev * B + bi) * 2 + d) * H + jo];
     }
-    const int chunk = MT * 64;                               // floats per workgroup per step
-    float *hxd = hx + (int64_t)d * 2 * NJ * chunk;
+    const int chunk = MT * 16 * UN;                          // floats per workgroup per step: [rows][UN]
+    float *hxd = hx + (int64_t)(d * NBT + bt) * 2 * NJ * chunk;
     __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(hxd, 0, 2 * NJ * chunk * 4, 0x00020000);
-    unsigned *fl = flags + d * NJ;
+    unsigned *fl = flags + (d * NBT + bt) * NJ;
     if (tid == 0) s_abort = 0;
     __syncthreads();
 
@@ -265,7 +274,10 @@ __global__ __launch_bounds__(256) void blstm_fwd_persist_kernel(
     // The set-up loads are consumed here: a load still pending at the loop entry would cost a
     // conservative queue drain in EVERY iteration.
 #pragma unroll
-    for (int f = 0; f < KQ4; ++f) asm volatile("" ::"v"(wreg[f].x), "v"(wreg[f].y), "v"(wreg[f].z), "v"(wreg[f].w));
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int f = 0; f < KQ4; ++f)
+            asm volatile("" ::"v"(wreg[nt][f].x), "v"(wreg[nt][f].y), "v"(wreg[nt][f].z), "v"(wreg[nt][f].w));
     asm volatile("" ::"v"(c), "v"(len));
     float sv[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};   // ig, fg, gg, og, c, h of the previous step
     int sv_g = OOB_OFF, sv_c = OOB_OFF, sv_h = OOB_OFF;   // their byte offsets
@@ -293,11 +305,11 @@ __global__ __launch_bounds__(256) void blstm_fwd_persist_kernel(
             float ig = 0.f, fg = 0.f, gg = 0.f, og = 0.f, cn = 0.f;
             if (valid && t < len) {
                 if (recur) {
-                    const int m = bi >> 4, r = bi & 15;
+                    const int m = bl >> 4, r = bl & 15, nt = u >> 2, uu = u & 3;
 #pragma unroll
                     for (int g = 0; g < 4; ++g)
-                        pre[g] += (red[s & 1][0][m][r][g * 4 + u] + red[s & 1][1][m][r][g * 4 + u]) +
-                                  (red[s & 1][2][m][r][g * 4 + u] + red[s & 1][3][m][r][g * 4 + u]);
+                        pre[g] += (red[s & 1][0][m][nt][r][g * 4 + uu] + red[s & 1][1][m][nt][r][g * 4 + uu]) +
+                                  (red[s & 1][2][m][nt][r][g * 4 + uu] + red[s & 1][3][m][nt][r][g * 4 + uu]);
                 }
                 ig = sigmoid_f(pre[0]); fg = sigmoid_f(pre[1]);
                 gg = tanh_f(pre[2]);    og = sigmoid_f(pre[3]);
@@ -307,13 +319,13 @@ __global__ __launch_bounds__(256) void blstm_fwd_persist_kernel(
             c = cn;   // padded rows keep a zero state (the reverse direction starts from it)
             // the 4 units of a batch row sit on 4 adjacent lanes: one 16-byte sc1 store per row
             const float h1 = __shfl_down(h, 1, 64), h2 = __shfl_down(h, 2, 64), h3 = __shfl_down(h, 3, 64);
-            if (u == 0 && !(dbg & 8)) {
+            if ((u & 3) == 0 && !(dbg & 8)) {
                 u32x4 pk = {__float_as_uint(h), __float_as_uint(h1), __float_as_uint(h2), __float_as_uint(h3)};
                 if (tagmode) {
                     const unsigned e = (unsigned)((s >> 1) & 1);
                     pk = u32x4{tag_bits(h, e), tag_bits(h1, e), tag_bits(h2, e), tag_bits(h3, e)};
                 }
-                __builtin_amdgcn_raw_buffer_store_b128(pk, rsrc, (((s & 1) * NJ + jt) * chunk + bi * 4) * 4, 0, 16);
+                __builtin_amdgcn_raw_buffer_store_b128(pk, rsrc, (((s & 1) * NJ + jt) * chunk + bl * UN + u) * 4, 0, 16);
             }
             sv[0] = ig; sv[1] = fg; sv[2] = gg; sv[3] = og; sv[4] = cn; sv[5] = h;
             sv_g = growb;
@@ -364,8 +376,8 @@ __global__ __launch_bounds__(256) void blstm_fwd_persist_kernel(
         for (int m = 0; m < MT; ++m)
 #pragma unroll
             for (int f = 0; f < KQ4; ++f) {
-                const int jtk = kb / 4 + f;
-                a[m][f] = ld4_sc1(rsrc, jtk < NJ ? (pbase + jtk * chunk + (m * 16 + i) * 4) * 4 : OOB_OFF);
+                const int k = kb + 4 * f;             // first of 4 consecutive units
+                a[m][f] = ld4_sc1(rsrc, k < H ? (pbase + (k / UN) * chunk + (m * 16 + i) * UN + k % UN) * 4 : OOB_OFF);
             }
         __builtin_amdgcn_sched_barrier(0);   // keep the issue order: loads return in order
 #pragma unroll
@@ -376,7 +388,7 @@ __global__ __launch_bounds__(256) void blstm_fwd_persist_kernel(
 #pragma unroll
         for (int m = 0; m < MT; ++m)
 #pragma unroll
-            for (int f = 0; f < KQ4; ++f) ok = ok & (tags_ok(a[m][f], want) | (kb / 4 + f >= NJ));
+            for (int f = 0; f < KQ4; ++f) ok = ok & (tags_ok(a[m][f], want) | (kb + 4 * f >= H));
         if (tagmode && !(dbg & 1)) {
             for (int spins = 0; !__all(ok); ++spins) {   // wave-uniform
                 if (spins >= SPIN_LIMIT) {
@@ -392,29 +404,31 @@ __global__ __launch_bounds__(256) void blstm_fwd_persist_kernel(
                 for (int m = 0; m < MT; ++m)
 #pragma unroll
                     for (int f = 0; f < KQ4; ++f) {
-                        const int jtk = kb / 4 + f;
-                        a[m][f] = ld4_sc1(rsrc, jtk < NJ ? (pbase + jtk * chunk + (m * 16 + i) * 4) * 4 : OOB_OFF);
+                        const int k = kb + 4 * f;
+                        a[m][f] = ld4_sc1(rsrc, k < H ? (pbase + (k / UN) * chunk + (m * 16 + i) * UN + k % UN) * 4 : OOB_OFF);
                     }
                 __builtin_amdgcn_sched_barrier(0);   // all loads in flight before the first check
 #pragma unroll
                 for (int m = 0; m < MT; ++m)
 #pragma unroll
-                    for (int f = 0; f < KQ4; ++f) ok = ok & (tags_ok(a[m][f], want) | (kb / 4 + f >= NJ));
+                    for (int f = 0; f < KQ4; ++f) ok = ok & (tags_ok(a[m][f], want) | (kb + 4 * f >= H));
             }
         }
 #pragma unroll
-        for (int m = 0; m < MT; ++m) {
-            f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+        for (int m = 0; m < MT; ++m)
 #pragma unroll
-            for (int f = 0; f < KQ4; ++f) {
-                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m][f].x, wreg[f].x, acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m][f].y, wreg[f].y, acc1, 0, 0, 0);
-                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m][f].z, wreg[f].z, acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m][f].w, wreg[f].w, acc1, 0, 0, 0);
+            for (int nt = 0; nt < NT; ++nt) {
+                f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int f = 0; f < KQ4; ++f) {
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m][f].x, wreg[nt][f].x, acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m][f].y, wreg[nt][f].y, acc1, 0, 0, 0);
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m][f].z, wreg[nt][f].z, acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m][f].w, wreg[nt][f].w, acc1, 0, 0, 0);
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) red[s & 1][wave][m][nt][q * 4 + r][i] = acc0[r] + acc1[r];
             }
-#pragma unroll
-            for (int r = 0; r < 4; ++r) red[s & 1][wave][m][q * 4 + r][i] = acc0[r] + acc1[r];
-        }
         // every wave consumes its gate loads here (not only the owner lanes): no load is left
         // pending across the loop's back edge, where the compiler would have to drain the
         // whole queue before reusing the registers
@@ -831,16 +845,18 @@ extern "C" int64_t asr_blstm_ws_floats(int B, int H) {
 // store drain -- results are then WRONG; never set by the product path.
 static int g_dbg = 0;
 static int g_bwd_form = 0;   // bit 8 of the debug flags selects the older dG-exchange kernel (A/B timing)
+static int g_fwd_form = 0;   // bit 10: forward kernel with both batch tiles in one workgroup (A/B timing)
 static int g_tagmode = 1;    // bit 9 selects the flag protocol instead of the in-band epoch tags
 extern "C" void asr_debug_set(int flags) {
     g_dbg = flags & 0xff;
     g_bwd_form = (flags >> 8) & 1;
     g_tagmode = ((flags >> 9) & 1) ? 0 : 1;
+    g_fwd_form = (flags >> 10) & 1;
 }
 
 static bool al16p(const void *p) { return (((uintptr_t)p) & 15) == 0; }
 
-template <int MT>
+template <int MT, int NT>
 static bool launch_fwd_persist(int kq4, dim3 grid, hipStream_t st, const float *W_hh, float *G, float *Cs,
                                float *Hout, int64_t ho_t, int64_t ho_b, const int32_t *lengths, int T, int B,
                                int H, int s0, int s1, float *hx, unsigned *flags, unsigned *err) {
@@ -848,8 +864,8 @@ static bool launch_fwd_persist(int kq4, dim3 grid, hipStream_t st, const float *
     const int64_t hout_bytes = ((int64_t)(T - 1) * ho_t + (int64_t)(B - 1) * ho_b + 2 * H) * 4;
 #define FWD_CASE(K)                                                                                       \
     case K:                                                                                               \
-        hipLaunchKernelGGL((blstm_fwd_persist_kernel<MT, K>), grid, dim3(256), 0, st, W_hh, G, Cs, Hout,  \
-                           ho_t, ho_b, hout_bytes, lengths, T, B, H, s0, s1, hx, flags, err, g_dbg,       \
+        hipLaunchKernelGGL((blstm_fwd_persist_kernel<MT, NT, K>), grid, dim3(256), 0, st, W_hh, G, Cs,    \
+                           Hout, ho_t, ho_b, hout_bytes, lengths, T, B, H, s0, s1, hx, flags, err, g_dbg, \
                            g_tagmode);                                                                    \
         return true;
     switch (kq4) {
@@ -885,11 +901,17 @@ extern "C" int asr_blstm_fwd_range(const float *W_hh, float *G, float *Cs, float
         if (g_tagmode)   // every exchanged float starts with the "wrong" epoch tag (LSB = 1)
             ASR_CHECK_HIP(hipMemsetAsync(hx, 0xFF, sizeof(float) * (size_t)4 * NJ * MT * 64, st));
     }
-    dim3 grid(NJ, 2);
-    bool ok = MT == 1 ? launch_fwd_persist<1>(kq4, grid, st, W_hh, G, Cs, Hout, ho_t, ho_b, lengths, T, B, H, s0,
-                                              s1, hx, flags, err)
-                      : launch_fwd_persist<2>(kq4, grid, st, W_hh, G, Cs, Hout, ho_t, ho_b, lengths, T, B, H, s0,
-                                              s1, hx, flags, err);
+    bool ok;
+    if (MT == 1) {
+        ok = launch_fwd_persist<1, 1>(kq4, dim3(NJ, 2, 1), st, W_hh, G, Cs, Hout, ho_t, ho_b, lengths, T, B, H, s0,
+                                      s1, hx, flags, err);
+    } else if (H % 8 == 0 && g_fwd_form == 0) {   // two batch tiles on separate workgroups of 8 units
+        ok = launch_fwd_persist<1, 2>(kq4, dim3(H / 8, 2, 2), st, W_hh, G, Cs, Hout, ho_t, ho_b, lengths, T, B, H,
+                                      s0, s1, hx, flags, err);
+    } else {
+        ok = launch_fwd_persist<2, 1>(kq4, dim3(NJ, 2, 1), st, W_hh, G, Cs, Hout, ho_t, ho_b, lengths, T, B, H, s0,
+                                      s1, hx, flags, err);
+    }
     ASR_CHECK_ARG(ok, "blstm_fwd: no persistent instantiation for H=%d", H);
     ASR_CHECK_LAUNCH("blstm_fwd_persist_kernel");
     return ASR_OK;

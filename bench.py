@@ -128,7 +128,7 @@ def roofline_probe(hp, dev):
     flops = T * 2 * (2.0 * B * H * 4 * H)
     out["blstm_fwd"] = {"bound": "mfma", "achieved": flops / dt / 1e12, "peak": MFMA_F32_PEAK_TFLOPS,
                         "unit": "TFLOP/s", "frac": flops / dt / 1e12 / MFMA_F32_PEAK_TFLOPS, "traffic": None,
-                        "kernel": "blstm_fwd_persist_kernel<2,5>", "shape": [T, B, H], "avg_us": dt * 1e6,
+                        "kernel": "blstm_fwd_persist_kernel<1,2,5>", "shape": [T, B, H], "avg_us": dt * 1e6,
                         "us_per_time_step": dt * 1e6 / T,
                         "note": "latency-bound recurrence: 500 dependent steps per launch"}
     # (2) input-projection GEMM of an upper encoder layer: (T*B x 2H) @ (2H x 4H), fp32 MFMA
