@@ -1286,40 +1286,72 @@ __global__ __launch_bounds__(256) void phase2_mfma_kernel(
             ph[n][r] = (av[n] && t < len) ? PH[((int64_t)b * T + t) * A + a] : 0.f;
         }
     }
-    // per-step inputs; every load is branch-free (clamped address, value masked)
-    struct In { float dev[4], fa[3], ff[4], sp[P3_NAT]; };
-    const int tA = min(tf + col, len - 1);
-    const bool tAv = tf + col < len;
-    int tq[4];
-    bool tqv[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) { tqv[r] = tf + 4 * q + r < len; tq[r] = min(tf + 4 * q + r, len - 1); }
-    auto load_in = [&](int s) -> In {
-        In in;
+    // Per-step inputs (the tile's 64 x 10 conv features, 64 energy gradients, 16*P3_NAT state
+    // projections) are staged through LDS once per workgroup -- loading them per lane costs ~13
+    // scattered vector-memory instructions per wave and step, which bound the first version.
+    // Double-buffered: step s+1's global loads are in flight under step s's math; one barrier
+    // per step.  Frames at or past the utterance length are staged as zeros.
+    // 16-byte loads of the contiguous [64][10] block: its offset ((s*B+b)*T + t0)*10 floats is a
+    // multiple of 4 when T is even (t0 is a multiple of 64)
+    const bool vecF = (T & 1) == 0 && (((uintptr_t)Fc) & 15) == 0;
+    float4 stF = zero4();
+    float stF1[3] = {0.f, 0.f, 0.f};
+    float stD = 0.f, stS = 0.f;
+    auto fetch = [&](int s) {
         const int64_t sb = (int64_t)s * B + b;
-        const float *dep = de + sb * T;
-        const float *fp = Fc + sb * T * NCH;
+        const float *fp = Fc + (sb * T + t0) * NCH;
+        const int nfl = (min(len, t0 + 64) - t0) * NCH;   // valid floats of the block
+        if (vecF) {
+            if (tid < 160) {
+                const int e = tid * 4;
+                if (e + 3 < nfl) {
+                    stF = ld4(fp + e);
+                } else {   // ragged end of the utterance inside this tile
+                    stF = make_float4(e < nfl ? fp[e] : 0.f, e + 1 < nfl ? fp[e + 1] : 0.f,
+                                      e + 2 < nfl ? fp[e + 2] : 0.f, 0.f);
+                }
+            }
+        } else {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const float v = dep[tq[r]];
-            in.dev[r] = tqv[r] ? v : 0.f;
-            const float f = fp[(int64_t)tq[r] * NCH + min(col, NCH - 1)];
-            in.ff[r] = (tqv[r] && col < NCH) ? f : 0.f;
+            for (int j = 0; j < 3; ++j) {
+                const int e = tid + 256 * j;
+                stF1[j] = (e < 640 && e < nfl) ? fp[e] : 0.f;
+            }
         }
-#pragma unroll
-        for (int ks = 0; ks < 3; ++ks) {
-            const int c = 4 * ks + q;
-            const float f = fp[(int64_t)tA * NCH + min(c, NCH - 1)];
-            in.fa[ks] = (tAv && c < NCH) ? f : 0.f;
+        if (tid >= 160 && tid < 224) {
+            const int t = t0 + tid - 160;
+            stD = t < len ? de[sb * T + t] : 0.f;
         }
-        const float *spp = sproj + sb * A;
-#pragma unroll
-        for (int n = 0; n < P3_NAT; ++n) {
-            const float v = spp[min(a_base + 16 * n + col, A - 1)];
-            in.sp[n] = av[n] ? v : 0.f;
+        if (tid < 16 * P3_NAT) {
+            const int a = a_base + tid;
+            stS = a < A ? sproj[sb * A + a] : 0.f;
         }
-        return in;
     };
+    __shared__ __attribute__((aligned(16))) float Fs[2][64][12];
+    __shared__ __attribute__((aligned(16))) float des[2][64];
+    __shared__ float sps[2][16 * P3_NAT];
+    auto stage = [&](int buf) {
+        if (vecF) {
+            if (tid < 160) {
+                const float w[4] = {stF.x, stF.y, stF.z, stF.w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int e = tid * 4 + j;
+                    Fs[buf][e / NCH][e % NCH] = w[j];
+                }
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const int e = tid + 256 * j;
+                if (e < 640) Fs[buf][e / NCH][e % NCH] = stF1[j];
+            }
+        }
+        if (tid >= 160 && tid < 224) des[buf][tid - 160] = stD;
+        if (tid < 16 * P3_NAT) sps[buf][tid] = stS;
+    };
+    // columns 10, 11 of Fs are the k-padding of the 12-wide products: zero once
+    for (int i2 = tid; i2 < 2 * 64; i2 += 256) { Fs[i2 >> 6][i2 & 63][10] = 0.f; Fs[i2 >> 6][i2 & 63][11] = 0.f; }
     float acc_ph[P3_NAT][4], acc_ee[P3_NAT];
     f32x4 acc_fe[P3_NAT];
 #pragma unroll
@@ -1329,27 +1361,39 @@ __global__ __launch_bounds__(256) void phase2_mfma_kernel(
 #pragma unroll
         for (int r = 0; r < 4; ++r) acc_ph[n][r] = 0.f;
     }
-    In cur = load_in(0);
+    fetch(0);
+    stage(0);
+    __syncthreads();
     for (int s = 0; s < L; ++s) {
-        const In nxt = load_in(min(s + 1, L - 1));   // next step's inputs in flight under this step's math
+        const int buf = s & 1;
+        if (s + 1 < L) fetch(s + 1);                       // uniform
+        const float4 dv = *reinterpret_cast<const float4 *>(&des[buf][16 * wave + 4 * q]);
+        const float dev[4] = {dv.x, dv.y, dv.z, dv.w};
+        float fa[3], ff[4];
+#pragma unroll
+        for (int ks = 0; ks < 3; ++ks) fa[ks] = Fs[buf][16 * wave + col][4 * ks + q];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) ff[r] = col < 12 ? Fs[buf][16 * wave + 4 * q + r][min(col, 11)] : 0.f;
 #pragma unroll
         for (int n = 0; n < P3_NAT; ++n) {
-            f32x4 x = {ph[n][0] + cur.sp[n], ph[n][1] + cur.sp[n], ph[n][2] + cur.sp[n], ph[n][3] + cur.sp[n]};
+            const float spv = sps[buf][16 * n + col];
+            f32x4 x = {ph[n][0] + spv, ph[n][1] + spv, ph[n][2] + spv, ph[n][3] + spv};
 #pragma unroll
-            for (int ks = 0; ks < 3; ++ks) x = __builtin_amdgcn_mfma_f32_16x16x4f32(cur.fa[ks], wfe[n][ks], x, 0, 0, 0);
+            for (int ks = 0; ks < 3; ++ks) x = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[ks], wfe[n][ks], x, 0, 0, 0);
             float dp[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const float th = tanh_f(x[r]);
-                dp[r] = cur.dev[r] * (1.f - th * th) * wee[n];
+                dp[r] = dev[r] * (1.f - th * th) * wee[n];
                 acc_ph[n][r] += dp[r];
-                acc_ee[n] += cur.dev[r] * th;
+                acc_ee[n] += dev[r] * th;
             }
 #pragma unroll
             for (int r = 0; r < 4; ++r)
-                acc_fe[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(cur.ff[r], dp[r], acc_fe[n], 0, 0, 0);
+                acc_fe[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(ff[r], dp[r], acc_fe[n], 0, 0, 0);
         }
-        cur = nxt;
+        if (s + 1 < L) stage(buf ^ 1);
+        __syncthreads();
     }
 #pragma unroll
     for (int n = 0; n < P3_NAT; ++n) {
