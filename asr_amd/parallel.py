@@ -17,10 +17,13 @@ from . import ops, streams
 
 
 class BucketedGradReducer:
-    def __init__(self, model, process_group=None):
+    def __init__(self, model, process_group=None, force=False):
+        """force: run the bucket machinery (hooks, packing, collective, mean) even in a group of
+        one -- a single-GPU rehearsal of the exact stream choreography the N-GPU job uses."""
         self.model = model
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self.active = self.world > 1 or (force and dist.is_initialized())
         enc, dec = model.encoder, model.decoder
         self.buckets = []                       # list of lists of parameters, in backward-completion order
         self.buckets.append(list(dec.parameters()))
@@ -38,15 +41,23 @@ class BucketedGradReducer:
         for bi, ps in enumerate(self.buckets):
             for p in ps:
                 self._where[p] = bi
-                if self.world > 1:
+                if self.active:
                     self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
 
     def broadcast_parameters(self, src=0):
         """One-time parameter broadcast from rank 0 (what DDP does at wrap time)."""
-        if self.world == 1:
+        if not self.active:
             return
         for p in self.model.parameters():
             dist.broadcast(p.data, src=src, group=self.group)
+
+    def _views(self, bi):
+        """The bucket's flat buffer as one view per parameter (same shapes as the gradients)."""
+        flat, out, o = self.flat[bi], [], 0
+        for p in self.buckets[bi]:
+            out.append(flat[o:o + p.numel()].view(p.shape))
+            o += p.numel()
+        return out
 
     def _on_grad(self, p):
         bi = self._where[p]
@@ -60,19 +71,30 @@ class BucketedGradReducer:
         if self.flat[bi] is None or self.flat[bi].numel() != n:
             self.flat[bi] = torch.empty(n, device=ps[0].device, dtype=torch.float32)
         flat = self.flat[bi]
-        if ps[0].is_cuda:
-            streams.wait_side(ps[0].device)      # weight gradients are produced on the side stream
-        o = 0
-        for p in ps:
-            flat[o:o + p.numel()].copy_(p.grad.reshape(-1))
-            o += p.numel()
-        # async_op: RCCL runs on the process group's own stream, ordered after the
-        # kernels enqueued so far; the backward keeps issuing work on this stream
-        self.work[bi] = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+
+        def pack_and_reduce():
+            # one multi-tensor copy per bucket, not one launch per parameter
+            torch._foreach_copy_(self._views(bi), [p.grad for p in ps])
+            # async_op: RCCL runs on the process group's own stream, ordered after the kernels
+            # enqueued so far on the CURRENT stream; the backward keeps issuing work meanwhile
+            self.work[bi] = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+
+        if ps[0].is_cuda and streams.ENABLED:
+            # The weight gradients are produced on the side stream (asr_amd/streams.py): pack and
+            # launch the bucket THERE, so the main stream -- the latency-bound recurrence chain --
+            # never waits for them.  The side stream first catches up with the main stream (the few
+            # gradients the main stream produced, and `flat`'s previous use in finish()).
+            dev = ps[0].device
+            side = streams.side_stream(dev)
+            side.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(side):
+                pack_and_reduce()
+        else:
+            pack_and_reduce()
 
     def finish(self):
         """Wait for every bucket, apply DDP's mean and scatter back into ``.grad``."""
-        if self.world == 1:
+        if not self.active:
             return
         for bi, ps in enumerate(self.buckets):
             if self.work[bi] is None:
@@ -86,10 +108,7 @@ class BucketedGradReducer:
                 ops.scale_(flat, 1.0 / self.world)
             else:
                 flat.mul_(1.0 / self.world)     # gloo/CPU rehearsal of the same bucket logic
-            o = 0
-            for p in ps:
-                p.grad.copy_(flat[o:o + p.numel()].view_as(p.grad))
-                o += p.numel()
+            torch._foreach_copy_([p.grad for p in ps], self._views(bi))
             self.work[bi] = None
             self._counts[bi] = 0
 

@@ -22,7 +22,11 @@ _tls = threading.local()
 def side_stream(device):
     s = _streams.get(device.index)
     if s is None:
-        s = torch.cuda.Stream(device=device)
+        # High priority on purpose: HIP multiplexes a process's streams onto few hardware queues, and
+        # once RCCL has created its (high-priority) streams a normal-priority stream created here
+        # lands on the SAME hardware queue as the main stream -- measured: the overlap vanishes
+        # (37.8 vs 35.4 ms per step).  A high-priority stream keeps a queue of its own.
+        s = torch.cuda.Stream(device=device, priority=-1)
         _streams[device.index] = s
     return s
 
@@ -36,7 +40,7 @@ def pipe_stream(device):
     two kinds of work never queue behind each other."""
     s = _pipes.get(device.index)
     if s is None:
-        s = torch.cuda.Stream(device=device)
+        s = torch.cuda.Stream(device=device, priority=-1)
         _pipes[device.index] = s
     return s
 

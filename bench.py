@@ -179,9 +179,11 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    force_dp = bool(os.environ.get("ASR_BENCH_FORCE_DP"))   # rehearsal: the N-GPU code path in a group of one
+    if world > 1 or force_dp:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
         backend = os.environ.get("ASR_BENCH_BACKEND", "nccl")     # "gloo": rehearsal on a 1-GPU box
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
@@ -202,7 +204,7 @@ def main():
     torch.manual_seed(1234)                      # identical weights on every rank
     model = AttModel(hp).to(dev).train()
     log('model built')
-    reducer = BucketedGradReducer(model)
+    reducer = BucketedGradReducer(model, force=force_dp)
     reducer.broadcast_parameters()
     log('parameters broadcast')
     x, lengths, tgt, tl = make_batch(hp, dev, seed=1234 + rank)
@@ -284,7 +286,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(make_hp(encoder_dropout=0.0))
         print(json.dumps(res), flush=True)
-    if world > 1:
+    if world > 1 or force_dp:
         import torch.distributed as dist
         dist.destroy_process_group()
 
