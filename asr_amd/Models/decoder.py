@@ -146,7 +146,7 @@ class _AttDecFunction(torch.autograd.Function):
             return out
 
         idx = t["targets"].t().contiguous().view(-1)
-        with streams.on_side(dev, S, g, drec, dyp, dsp, dPH, hbatch, idx):
+        with streams.on_side(dev, S, g, drec, dyp, dsp, dPH, hbatch, idx, params=tuple(P.values())):
             G["W_gs"] = tn(drec2, g2)
             G["W_ss"] = tn(drec2, S_in)
             G["b_gs"] = torch.empty(4 * Hd, **f32)

@@ -192,6 +192,7 @@ class _BLSTMLayerFunction(torch.autograd.Function):
             nxt.G = G_n
         ctx.save_for_backward(inp, G, Cs, Hout, lengths_dev, w_ih_f, w_hh_f, w_ih_r, w_hh_r)
         ctx.mask = mask
+        ctx.wparams = (w_ih_f, w_hh_f, b_ih_f, b_hh_f, w_ih_r, w_hh_r, b_ih_r, b_hh_r)
         ctx.p = nxt.p if mask is not None else 0.0
         ctx.dims = (B, T, D, H, first, in_two, ho_t, ho_b)
         return out
@@ -256,7 +257,7 @@ class _BLSTMLayerFunction(torch.autograd.Function):
         # next layer's (latency-bound) recurrence kernel
         hout_two = (B, ho_b, ho_t)                 # row (t*B + b) <-> Hout element offset
         grads = {}
-        with streams.on_side(dev, G, inp, Hout):
+        with streams.on_side(dev, G, inp, Hout, params=ctx.wparams):
             db = torch.empty(8 * H, **f32)
             ops.colsum(dG, db)                     # b_ih and b_hh receive the same column sums
             for d in range(2):

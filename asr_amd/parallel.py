@@ -24,6 +24,8 @@ class BucketedGradReducer:
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         self.active = self.world > 1 or (force and dist.is_initialized())
+        # this reducer is stream-aware (see _launch): the weight gradients may be produced on the side stream
+        streams.enable(True)
         enc, dec = model.encoder, model.decoder
         self.buckets = []                       # list of lists of parameters, in backward-completion order
         self.buckets.append(list(dec.parameters()))

@@ -14,7 +14,19 @@ import threading
 
 import torch
 
-ENABLED = os.environ.get("ASR_SIDE_STREAM", "1") != "0"
+# Off until a stream-aware owner of the gradients turns it on (BucketedGradReducer does; so can a
+# training loop that only reads .grad after backward() has returned): anything that reads a
+# gradient the moment autograd hands it over -- stock DistributedDataParallel's bucket hooks --
+# would read it before the side stream has written it.  ASR_SIDE_STREAM=0 keeps it off (A/B timing).
+ENABLED = False
+_FORCED_OFF = os.environ.get("ASR_SIDE_STREAM", "1") == "0"
+
+
+def enable(flag=True):
+    global ENABLED
+    ENABLED = bool(flag) and not _FORCED_OFF
+
+
 _streams = {}
 _tls = threading.local()
 
@@ -65,17 +77,21 @@ def wait_side(device):
 
 
 class on_side:
-    """with on_side(device, *tensors): ... -- run the block on the side stream, ordered after
-    everything enqueued on the current stream so far; `tensors` were allocated on the main
-    stream and are read by the block (their memory must not be recycled under it)."""
+    """with on_side(device, *tensors, params=...): ... -- run the block on the side stream, ordered
+    after everything enqueued on the current stream so far; `tensors` were allocated on the main
+    stream and are read by the block (their memory must not be recycled under it); `params` are
+    the parameters whose gradients the block produces."""
 
-    def __init__(self, device, *tensors):
+    def __init__(self, device, *tensors, params=()):
         self.device = device
         self.tensors = tensors
+        self.params = params
         self.ctx = None
 
     def __enter__(self):
-        if not ENABLED:
+        # a parameter that already holds a gradient gets the new one ADDED by autograd on the main
+        # stream as soon as this backward node returns (gradient accumulation): stay on the main stream
+        if not ENABLED or any(p.grad is not None for p in self.params):
             return self
         side = side_stream(self.device)
         ev = torch.cuda.Event()

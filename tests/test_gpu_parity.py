@@ -293,6 +293,40 @@ def test_golden_forward_backward(name):
 
 
 @pytest.mark.parametrize("name", CASES)
+def test_golden_forward_backward_with_side_stream(name):
+    """The same golden check with the weight gradients produced on the side stream
+    (asr_amd/streams.py, what bench.py and BucketedGradReducer turn on), then a second backward
+    without clearing .grad: with a gradient already in place the new one is added by autograd on
+    the main stream, so the block must fall back to the main stream -- the sum is exactly 2x."""
+    from asr_amd import streams
+    from asr_amd.Loss.label_smoothing import label_smoothing_loss
+    z, hp = load_case(name)
+    dev = _dev()
+    m = _build(hp, params_of(z))
+    lengths = torch.from_numpy(z["lengths"])
+    targets = torch.from_numpy(z["targets"]).to(dev)
+    tl = torch.from_numpy(z["text_lengths"]).to(dev)
+    streams.enable(True)
+    try:
+        assert streams.ENABLED
+        x = torch.from_numpy(z["x"]).to(dev).requires_grad_(True)
+        loss = label_smoothing_loss(m(x, lengths, targets), targets, tl, hp.T_norm, hp.B_norm)
+        loss.backward()
+        assert rel_err(x.grad.cpu(), z["f64.dx"]) < GRAD_TOL
+        first = {}
+        for k, p in m.named_parameters():
+            first[k] = p.grad.cpu().clone()          # .cpu() on the main stream: the join must have happened
+            assert rel_err(first[k], z[f"f64.grad.{k}"]) < GRAD_TOL, k
+        x2 = torch.from_numpy(z["x"]).to(dev).requires_grad_(True)
+        loss2 = label_smoothing_loss(m(x2, lengths, targets), targets, tl, hp.T_norm, hp.B_norm)
+        loss2.backward()                              # accumulates into the existing .grad
+        for k, p in m.named_parameters():
+            assert rel_err(p.grad.cpu(), 2.0 * first[k]) < 1e-5, k
+    finally:
+        streams.enable(False)
+
+
+@pytest.mark.parametrize("name", CASES)
 def test_golden_greedy_tokens(name):
     z, hp = load_case(name)
     dev = _dev()
