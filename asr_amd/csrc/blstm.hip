@@ -729,7 +729,9 @@ __global__ __launch_bounds__(256) void blstm_bwd_rs_kernel(
     const int item = tid % NI, grp = tid / NI;
     const int ib = item / (UW / 4), ih = item % (UW / 4);
     const int jj = j0 + 4 * ih;                  // first unit of this item
-    constexpr int CH = 8;
+    // sources per thread group: NJT <= 4*NMT*(16/UW) and NG = 64/UW*... = 256/NI groups -> NMT loads each
+    constexpr int CH = NMT;
+    static_assert(CH <= 8, "exchange loads per lane");
     for (; s < s1; ++s) {
         const int t = d == 0 ? T - 1 - s : s;
         const bool act = valid && t < len;
@@ -748,8 +750,8 @@ __global__ __launch_bounds__(256) void blstm_bwd_rs_kernel(
         }
         // sum the NJT partial products of the previous step: every thread issues its share of
         // the 16-byte loads at once (one memory round trip), then a fixed-order reduction
-        // through LDS.  The first CH*NG sources take the fast path below; more (H > 512 with
-        // UW = 8) are swept by the loop after it.
+        // through LDS.  CH*NG >= NJT by construction; the sweep loop after the fast path is a
+        // safety net only.
         const int off0 = (int)((((s - 1) & 1) * slotf + ((int64_t)(jj >> 4) * 16 + ib) * 16 + (jj & 15)) * 4);
         const unsigned want = (unsigned)(((s - 1) >> 1) & 1);
         float4 v[CH];
