@@ -389,21 +389,28 @@ def test_librispeech_dims_small_batch_vs_oracle():
         assert rel_err(p.grad.cpu(), q.grad) < GRAD_TOL, k
 
 
-def test_full_size_properties():
-    """BASELINE config 2 (B=32, T=500 stacked, L=100, V=1000, 5 layers): too slow for
+@pytest.mark.parametrize("cfg", ["config2_librispeech", "config4_csj"])
+def test_full_size_properties(cfg):
+    """BASELINE config 2 (B=32, T=500 stacked, L=100, V=1000, 5 layers) and config 4 (CSJ:
+    40-dim fbank -> D=120, T_mel linspace(2400,1200) -> T=800, V=7000, L=150): too slow for
     the CPU oracle, so check size-independent properties: padded encoder rows are
-    exactly zero, every alignment row sums to 1 over the valid frames and is 0 past
-    them, the loss is finite, gradients are finite, and the gradient of the loss
+    exactly zero, the loss is finite, gradients are finite, and the gradient of the loss
     along a random parameter direction matches a central finite difference."""
     from asr_amd.Loss.label_smoothing import label_smoothing_loss
     from asr_amd.Models.AttModel import AttModel
     from oracle import ref_model as R
     from bench import make_batch
     dev = _dev()
-    hp = R.make_hp(encoder_dropout=0.0)
     torch.manual_seed(1234)
-    m = AttModel(hp).to(dev).train()
-    x, lengths, tgt, tl = make_batch(hp, dev, seed=1234)
+    if cfg == "config2_librispeech":
+        hp = R.make_hp(encoder_dropout=0.0)
+        m = AttModel(hp).to(dev).train()
+        x, lengths, tgt, tl = make_batch(hp, dev, seed=1234)
+    else:
+        hp = R.make_hp(lmfb_dim=40, num_classes=7000, encoder_dropout=0.0)
+        m = AttModel(hp).to(dev).train()
+        x, lengths, tgt, tl = make_batch(hp, dev, seed=1234, t_hi=2400, t_lo=1200, L=150, l_lo=75)
+        assert x.shape == (32, 800, 120)
     y = m(x, lengths, tgt)
     loss = label_smoothing_loss(y, tgt, tl)
     loss.backward()
