@@ -32,6 +32,13 @@ class GemmDesc(C.Structure):
     ]
 
 
+TENSOR_LIST_MAX = 48
+
+
+class TensorList(C.Structure):
+    _fields_ = [("count", C.c_int), ("p", c_f * TENSOR_LIST_MAX), ("n", c_i64 * TENSOR_LIST_MAX)]
+
+
 class AttDecFwdArgs(C.Structure):
     _fields_ = [
         ("B", C.c_int), ("T", C.c_int), ("E", C.c_int), ("Hd", C.c_int), ("L", C.c_int), ("V", C.c_int),
@@ -68,6 +75,9 @@ SYMBOLS = {
     "asr_scatter_rows": (C.c_int, [c_f, c_f, C.c_int, C.c_int, c_i64, c_f, C.c_int, c_f]),
     "asr_mul_dtanh": (C.c_int, [c_f, c_f, c_f, c_i64, c_f]),
     "asr_scale": (C.c_int, [c_f, c_i64, C.c_float, c_f]),
+    "asr_sqnorm_ws_floats": (c_i64, []),
+    "asr_grad_sqnorm": (C.c_int, [C.POINTER(TensorList), c_f, C.c_int, c_f, c_f]),
+    "asr_clip_adam_step": (C.c_int, [C.POINTER(TensorList)] * 4 + [c_f] + [C.c_double] * 6 + [c_i64, c_f]),
     "asr_blstm_ws_floats": (c_i64, [C.c_int, C.c_int]),
     "asr_blstm_fwd": (C.c_int, [c_f, c_f, c_f, c_f, c_i64, c_i64, c_f, C.c_int, C.c_int, C.c_int, c_f, c_f]),
     "asr_blstm_bwd": (C.c_int, [c_f, c_f, c_f, c_f, c_f, c_i64, c_i64, c_f, c_f, C.c_int, C.c_int, C.c_int,

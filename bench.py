@@ -209,7 +209,9 @@ def main():
     log('parameters broadcast')
     x, lengths, tgt, tl = make_batch(hp, dev, seed=1234 + rank)
     frames = make_batch.mel_frames
-    opt = torch.optim.Adam(model.parameters(), lr=hp.lr, weight_decay=1e-5)
+    from asr_amd.optim import ClipAdam
+    opt = ClipAdam(model.parameters(), lr=hp.lr, weight_decay=1e-5)          # fused clip + Adam
+    opt_stock = torch.optim.Adam(model.parameters(), lr=hp.lr, weight_decay=1e-5)
 
     def step():
         for p in model.parameters():
@@ -249,20 +251,28 @@ def main():
         total_frames = float(frames)
     ms = dt / args.steps * 1e3
 
-    # full optimiser step (clip + Adam, train.py:60-63), reported beside the metric
-    full_ms = None
-    if rank == 0 or world > 1:
+    # full optimiser step (clip + Adam, train.py:60-63), reported beside the metric: with the fused
+    # asr_amd.optim.ClipAdam, and with the reference's stock clip_grad_norm_ + torch.optim.Adam
+    def time_full(update):
         step()                                   # untimed: optimiser state + first-use kernel loads
-        torch.nn.utils.clip_grad_norm_(model.parameters(), hp.clip)
-        opt.step()
+        update()
         barrier()
+        n = max(2, args.steps // 2)
         t0 = time.perf_counter()
-        for _ in range(max(2, args.steps // 2)):
+        for _ in range(n):
             step()
-            torch.nn.utils.clip_grad_norm_(model.parameters(), hp.clip)
-            opt.step()
+            update()
         barrier()
-        full_ms = (time.perf_counter() - t0) / max(2, args.steps // 2) * 1e3
+        return (time.perf_counter() - t0) / n * 1e3
+
+    def stock_update():
+        torch.nn.utils.clip_grad_norm_(model.parameters(), hp.clip)
+        opt_stock.step()
+
+    full_ms = full_stock_ms = None
+    if rank == 0 or world > 1:
+        full_ms = time_full(lambda: opt.step(max_norm=hp.clip))
+        full_stock_ms = time_full(stock_update)
 
     if rank == 0:
         res = {
@@ -278,6 +288,7 @@ def main():
                        "encoder_dropout": args.dropout, "loss": float(loss)},
             "stacked_frames_per_s": total_frames / 3.0 / (ms * 1e-3),
             "full_step_ms_with_clip_adam": full_ms,
+            "full_step_ms_with_stock_clip_adam": full_stock_ms,
         }
         probes = roofline_probe(hp, dev) if world == 1 else {}
         if probes:

@@ -109,6 +109,34 @@ int asr_mul_dtanh(const float *dU, const float *U, float *out, int64_t n, void *
 /* x *= s (1/world_size after the gradient all-reduce: DDP averages, train.py:141) */
 int asr_scale(float *x, int64_t n, float s, void *stream);
 
+/* ------------------------------------------------- optimizer step (next) --
+ * The caller-side tail of the step, train.py:60-63 with the optimizer built at train.py:146:
+ *   torch.nn.utils.clip_grad_norm_(model.parameters(), hp.clip)     -> asr_grad_sqnorm
+ *   torch.optim.Adam(lr, weight_decay=1e-5).step()                   -> asr_clip_adam_step
+ * A tensor list travels by value (device pointers + element counts, at most
+ * ASR_TENSOR_LIST_MAX per call; longer lists are passed in several calls, the squared norm
+ * accumulated with accumulate != 0).  Nothing synchronises with the host: the clip
+ * coefficient min(1, max_norm / (sqrt(norm2) + 1e-6)) is computed on the device. */
+#define ASR_TENSOR_LIST_MAX 48
+typedef struct asr_tensor_list {
+    int count;
+    float *p[ASR_TENSOR_LIST_MAX];
+    int64_t n[ASR_TENSOR_LIST_MAX];
+} asr_tensor_list;
+/* norm2[0] (+)= sum over all listed tensors of the sum of squares (deterministic two-stage
+ * sum; ws: asr_sqnorm_ws_floats() floats of scratch). */
+int64_t asr_sqnorm_ws_floats(void);
+int asr_grad_sqnorm(const asr_tensor_list *grads, float *norm2, int accumulate, float *ws, void *stream);
+/* One Adam step (torch.optim.Adam semantics: coupled L2 weight decay, bias correction, no
+ * amsgrad) on every listed tensor, with the gradients first scaled by the clip coefficient
+ * (max_norm <= 0: no clipping, norm2 may be NULL) and written back scaled, as clip_grad_norm_
+ * does.  step counts from 1.  Hyper-parameters are doubles (Python floats in torch): 1 - beta
+ * and the bias corrections are formed in double and rounded to fp32 once, as torch does. */
+int asr_clip_adam_step(const asr_tensor_list *params, const asr_tensor_list *grads,
+                       const asr_tensor_list *exp_avg, const asr_tensor_list *exp_avg_sq,
+                       const float *norm2, double max_norm, double lr, double beta1, double beta2,
+                       double eps, double weight_decay, int64_t step, void *stream);
+
 /* ----------------------------------------------------------------- BLSTM --
  * One bidirectional LSTM layer over a ragged batch WITHOUT packing: the
  * recurrence of torch.nn.LSTM as called by Models/encoder.py:32-34

@@ -505,3 +505,50 @@ def test_dropout_between_layers():
     xg = xin.clone().requires_grad_(True)
     enc(xg, lens).sum().backward()
     assert torch.isfinite(xg.grad).all()
+
+
+# ------------------------------------------------ optimizer step --
+@pytest.mark.parametrize("max_norm", [5.0, 0.05, None])
+def test_clip_adam_vs_torch(max_norm):
+    """asr_grad_sqnorm + asr_clip_adam_step against torch.nn.utils.clip_grad_norm_ +
+    torch.optim.Adam(weight_decay=1e-5) (train.py:60-63,146) in float64 on the CPU: four steps on
+    tensors of awkward sizes (1 element, odd, > one block's stride); max_norm 5.0 does not clip
+    these gradients, 0.05 does.  Tolerance 2e-6 relative (fp32 update of O(1) parameters)."""
+    from asr_amd.optim import ClipAdam
+    dev = _dev()
+    torch.manual_seed(3)
+    shapes = [(1,), (7,), (33, 5), (1280, 640), (1000, 1281), (3, 4, 5)]
+    ps = [torch.randn(*sh) for sh in shapes]
+    ref = [torch.nn.Parameter(p.double().clone()) for p in ps]
+    got = [torch.nn.Parameter(p.clone().to(dev)) for p in ps]
+    ropt = torch.optim.Adam(ref, lr=1e-3, weight_decay=1e-5)
+    gopt = ClipAdam(got, lr=1e-3, weight_decay=1e-5)
+    for step in range(4):
+        gs = [torch.randn(*sh) * (0.1 + step) for sh in shapes]
+        for p, q, g in zip(ref, got, gs):
+            p.grad = g.double().clone()
+            q.grad = g.clone().to(dev)
+        if max_norm is not None:
+            tn = torch.nn.utils.clip_grad_norm_(ref, max_norm)
+        ropt.step()
+        out = gopt.step(max_norm=max_norm)
+        if max_norm is not None:
+            assert abs(float(out) - float(tn)) / float(tn) < 1e-6
+            for p, q in zip(ref, got):                      # the clipped gradient is written back
+                assert rel_err(q.grad.cpu(), p.grad) < 2e-6
+        for p, q in zip(ref, got):
+            assert rel_err(q.detach().cpu(), p.detach()) < 2e-6
+            assert rel_err(gopt.state[q]["exp_avg"].cpu(), ropt.state[p]["exp_avg"]) < 2e-6
+            assert rel_err(gopt.state[q]["exp_avg_sq"].cpu(), ropt.state[p]["exp_avg_sq"]) < 2e-6
+    # state_dict layout is torch.optim.Adam's: it loads into a stock Adam on the same parameters
+    stock = torch.optim.Adam(got, lr=1e-3, weight_decay=1e-5)
+    stock.load_state_dict(gopt.state_dict())
+    assert int(stock.state[got[0]]["step"]) == 4
+
+
+def test_clip_adam_rejects_cpu_parameters():
+    from asr_amd.optim import ClipAdam
+    p = torch.nn.Parameter(torch.randn(4))
+    p.grad = torch.randn(4)
+    with pytest.raises(RuntimeError):
+        ClipAdam([p]).step()
