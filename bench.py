@@ -127,7 +127,10 @@ def roofline_probe(hp, dev):
     # all B rows run all T steps in the kernel (padded rows are masked, not skipped)
     flops = T * 2 * (2.0 * B * H * 4 * H)
     out["blstm_fwd"] = {"bound": "mfma", "achieved": flops / dt / 1e12, "peak": MFMA_F32_PEAK_TFLOPS,
-                        "unit": "TFLOP/s", "frac": flops / dt / 1e12 / MFMA_F32_PEAK_TFLOPS, "traffic": None,
+                        "unit": "TFLOP/s", "frac": flops / dt / 1e12 / MFMA_F32_PEAK_TFLOPS,
+                        # PMC passes of this kernel at this shape (profiles/r1_pmc_blstm.txt): 2 x FETCH_SIZE
+                        # (gfx950 correction for 16-B streams) + WRITE_SIZE, bytes per launch, fabric side
+                        "traffic": 2 * 486757e3 + 280000e3,
                         "kernel": "blstm_fwd_persist_kernel<1,2,5>", "shape": [T, B, H], "avg_us": dt * 1e6,
                         "us_per_time_step": dt * 1e6 / T,
                         "note": "latency-bound recurrence: 500 dependent steps per launch"}
