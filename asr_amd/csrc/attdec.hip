@@ -672,14 +672,7 @@ __global__ __launch_bounds__(E2W * 64) void energy_bwd2_kernel(
                 }
                 // dsproj[a] partial: sum over the 16 frames of this tile (the 16 lanes with equal q)
         #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    float v = dp[r];
-                    v += __shfl_xor(v, 8, 64);
-                    v += __shfl_xor(v, 4, 64);
-                    v += __shfl_xor(v, 2, 64);
-                    v += __shfl_xor(v, 1, 64);
-                    dp[r] = v;
-                }
+                for (int r = 0; r < 4; ++r) dp[r] = row16_sum(dp[r]);
                 if (col == 0) *reinterpret_cast<float4 *>(m.dspl + tt * A16 + 16 * mt + 4 * q) = make_float4(dp[0], dp[1], dp[2], dp[3]);
             }
         }

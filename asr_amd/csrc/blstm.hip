@@ -318,7 +318,9 @@ __global__ __launch_bounds__(256) void blstm_fwd_persist_kernel(
             }
             c = cn;   // padded rows keep a zero state (the reverse direction starts from it)
             // the 4 units of a batch row sit on 4 adjacent lanes: one 16-byte sc1 store per row
-            const float h1 = __shfl_down(h, 1, 64), h2 = __shfl_down(h, 2, 64), h3 = __shfl_down(h, 3, 64);
+            // quad broadcasts on the VALU (DPP), not three trips through the LDS crossbar: the storing lane
+            // is lane 0 of its quad (UN is a multiple of 4)
+            const float h1 = ASR_DPP(h, 0x55), h2 = ASR_DPP(h, 0xAA), h3 = ASR_DPP(h, 0xFF);
             if ((u & 3) == 0 && !(dbg & 8)) {
                 u32x4 pk = {__float_as_uint(h), __float_as_uint(h1), __float_as_uint(h2), __float_as_uint(h3)};
                 if (tagmode) {

@@ -46,9 +46,23 @@ void asr_set_error(const char *fmt, ...);
     } while (0)
 
 // ------------------------------------------------------------ device math --
+// Sum over the 16 lanes of a DPP row (lanes with equal lane>>4), result in every lane of the row.
+// Data-parallel-primitive modifiers on the adds themselves (row rotate by 8 and 4, quad
+// permutes): 4 VALU instructions, no trip through the LDS crossbar (__shfl_xor compiles to
+// ds_bpermute_b32 + a wait on gfx9).
+#define ASR_DPP(v, ctrl) \
+    __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), (ctrl), 0xF, 0xF, true))
+__device__ __forceinline__ float row16_sum(float v) {
+    v += ASR_DPP(v, 0x128);   // row_ror:8
+    v += ASR_DPP(v, 0x124);   // row_ror:4
+    v += ASR_DPP(v, 0x4E);    // quad_perm:[2,3,0,1]
+    v += ASR_DPP(v, 0xB1);    // quad_perm:[1,0,3,2]
+    return v;
+}
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    v = row16_sum(v);
+    v += __shfl_xor(v, 16, 64);
+    v += __shfl_xor(v, 32, 64);
     return v;
 }
 __device__ __forceinline__ float wave_max(float v) {
