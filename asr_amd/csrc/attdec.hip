@@ -656,24 +656,21 @@ __global__ __launch_bounds__(E2W * 64) void energy_bwd2_kernel(
                 const f32x4 acc = e2_pre(m, mt, q, col, ph[jx], fB);
                 const float4 w4 = *reinterpret_cast<const float4 *>(m.wee + 16 * mt + 4 * q);
                 float dp[4];
-                {
-                    const float t0h = tanh_f(acc[0]), t1h = tanh_f(acc[1]), t2h = tanh_f(acc[2]), t3h = tanh_f(acc[3]);
-                    dp[0] = de * w4.x * (1.f - t0h * t0h);
-                    dp[1] = de * w4.y * (1.f - t1h * t1h);
-                    dp[2] = de * w4.z * (1.f - t2h * t2h);
-                    dp[3] = de * w4.w * (1.f - t3h * t3h);
-                }
+                dp[0] = (de * w4.x) * sech2_f(acc[0]);
+                dp[1] = (de * w4.y) * sech2_f(acc[1]);
+                dp[2] = (de * w4.z) * sech2_f(acc[2]);
+                dp[3] = (de * w4.w) * sech2_f(acc[3]);
                 // dF^T[c][t] += sum_a W_fe[a][c] dpre[t][a]: k-step r pairs a = 16mt + 4q + r on both operands
-                const float *wcol = m.wfe + (16 * mt + 4 * q) * 12 + col;   // col >= 12 reads the next row: masked below
+                // (columns 12..15 read into the next table row -- still inside the LDS tables, finite --
+                // and only feed rows c >= 12 of dF^T, which nobody reads: no mask, no branch)
+                const float *wcol = m.wfe + (16 * mt + 4 * q) * 12 + col;
         #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float av = col < 12 ? wcol[r * 12] : 0.f;
-                    dFacc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, dp[r], dFacc, 0, 0, 0);
-                }
-                // dsproj[a] partial: sum over the 16 frames of this tile (the 16 lanes with equal q)
-        #pragma unroll
-                for (int r = 0; r < 4; ++r) dp[r] = row16_sum(dp[r]);
-                if (col == 0) *reinterpret_cast<float4 *>(m.dspl + tt * A16 + 16 * mt + 4 * q) = make_float4(dp[0], dp[1], dp[2], dp[3]);
+                for (int r = 0; r < 4; ++r)
+                    dFacc = __builtin_amdgcn_mfma_f32_16x16x4f32(wcol[r * 12], dp[r], dFacc, 0, 0, 0);
+                // dsproj[a] partial: sum over the 16 frames of this tile (the 16 lanes with equal q);
+                // lane col ends up with the total of a = 16 mt + 4 q + (col >> 2)
+                const float tot = row16_sum4(dp[0], dp[1], dp[2], dp[3]);
+                if ((col & 3) == 0) m.dspl[tt * A16 + 16 * mt + 4 * q + (col >> 2)] = tot;
             }
         }
     }

@@ -59,6 +59,23 @@ __device__ __forceinline__ float row16_sum(float v) {
     v += ASR_DPP(v, 0xB1);    // quad_perm:[1,0,3,2]
     return v;
 }
+// Sums of FOUR values over the 16 lanes of a DPP row in 5 DPP adds + 6 selects (instead of
+// 4 x 4): a butterfly that halves the number of live values at each of the first two steps.
+// Returns, in lane c of the row, the row total of v[c >> 2] (each total replicated on 4 lanes).
+// Pairings: +8 (row_ror:8), mirror within 8 lanes (flips bit 2), then xor 2 and xor 1.
+__device__ __forceinline__ float row16_sum4(float v0, float v1, float v2, float v3) {
+    const int c = threadIdx.x & 15;
+    const bool hi = (c & 8) != 0, mid = (c & 4) != 0;
+    const float s0 = hi ? v0 : v2, s1 = hi ? v1 : v3;      // what the partner keeps
+    const float k0 = hi ? v2 : v0, k1 = hi ? v3 : v1;      // what this lane keeps
+    const float u0 = k0 + ASR_DPP(s0, 0x128);              // row_ror:8
+    const float u1 = k1 + ASR_DPP(s1, 0x128);
+    const float s = mid ? u0 : u1, k = mid ? u1 : u0;
+    float w = k + ASR_DPP(s, 0x141);                       // row_half_mirror
+    w += ASR_DPP(w, 0x4E);                                 // quad_perm:[2,3,0,1]
+    w += ASR_DPP(w, 0xB1);                                 // quad_perm:[1,0,3,2]
+    return w;
+}
 __device__ __forceinline__ float wave_sum(float v) {
     v = row16_sum(v);
     v += __shfl_xor(v, 16, 64);
@@ -83,6 +100,14 @@ __device__ __forceinline__ float fast_exp(float x) {
 __device__ __forceinline__ float tanh_f(float x) {
     const float e = __builtin_amdgcn_exp2f(x * 2.88539008177792681472f);
     return __builtin_fmaf(-2.0f, __builtin_amdgcn_rcpf(1.0f + e), 1.0f);
+}
+
+// 1 - tanh(x)^2 = 4 e / (1 + e)^2 with e = exp(-2|x|) in (0, 1]: no overflow, no tanh needed
+// (3 VALU multiplies + add + 2 transcendental; |x| and the sign are free operand modifiers).
+__device__ __forceinline__ float sech2_f(float x) {
+    const float e = __builtin_amdgcn_exp2f(fabsf(x) * -2.88539008177792681472f);
+    const float r = __builtin_amdgcn_rcpf(1.0f + e);
+    return 4.0f * (e * r) * r;
 }
 
 // sigmoid as torch.nn.LSTM computes it, 1/(1+exp(-x))
