@@ -13,6 +13,7 @@ either way.
 import torch
 import torch.nn as nn
 
+from ..utils.utils import lengths_to_device
 from .decoder import Decoder
 from .encoder import Encoder
 
@@ -32,6 +33,8 @@ class AttModel(nn.Module):
         self.decoder = Decoder(hp)
 
     def forward(self, x, lengths, targets, src_pos=None):
+        # one asynchronous host -> device hand-over of the lengths for both halves of the model
+        lengths = lengths_to_device(lengths, x.device)
         hbatch = self.encoder(x, lengths)
         return self.decoder(hbatch, lengths, targets)
 

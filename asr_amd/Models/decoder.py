@@ -14,6 +14,7 @@ import torch.nn as nn
 
 from .. import _lib, ops, streams
 from .._lib import AttDecBwdArgs, AttDecFwdArgs, check
+from ..utils.utils import lengths_to_device
 from .attention import Attention
 
 NC, KW = 10, 100
@@ -195,7 +196,7 @@ class Decoder(nn.Module):
     def forward(self, hbatch, lengths, targets):
         if not hbatch.is_cuda:
             raise RuntimeError("asr_amd.Decoder: input must be on the GPU; the HIP path has no CPU fallback")
-        lengths_dev = lengths.to(device=hbatch.device, dtype=torch.int32)
+        lengths_dev = lengths_to_device(lengths, hbatch.device)
         return _AttDecFunction.apply(hbatch, lengths_dev, targets, *self._params())
 
     @torch.no_grad()

@@ -16,6 +16,7 @@ import torch.nn as nn
 
 from .. import _lib, ops, streams
 from .._lib import check
+from ..utils.utils import lengths_to_device
 
 
 class BiLSTMParams(nn.Module):
@@ -324,7 +325,7 @@ class Encoder(nn.Module):
     def forward(self, x, lengths):
         if not x.is_cuda:
             raise RuntimeError("asr_amd.Encoder: input must be on the GPU; the HIP path has no CPU fallback")
-        lengths_dev = lengths.to(device=x.device, dtype=torch.int32)
+        lengths_dev = lengths_to_device(lengths, x.device)
         p = self.dropout if self.training else 0.0
         seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if p > 0.0 else 0
         h = x.float()

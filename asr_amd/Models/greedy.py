@@ -22,7 +22,8 @@ def greedy_decode(dec, hbatch, lengths, max_len, eos_id):
         [p.detach() for p in dec._params()]
     Hd = W_sy.shape[0]
     A, V, L = 2 * Hd, W_yy.shape[0], int(max_len)
-    lengths_dev = lengths.to(device=dev, dtype=torch.int32)
+    from ..utils.utils import lengths_to_device
+    lengths_dev = lengths_to_device(lengths, dev)
     PH = torch.empty(B, T, A, **f32)
     ops.linear_nt(hbatch.view(B * T, E), W_he, PH.view(B * T, A), bias1=b_he)
     tokens = torch.zeros(1, L, device=dev, dtype=torch.int64)
