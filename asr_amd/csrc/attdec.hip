@@ -434,30 +434,43 @@ __global__ __launch_bounds__(256) void e2_prep_kernel(const float *__restrict__ 
 
 // tab = [wfe_pad (A16*12) | wee_pad (A16)] in global memory; m.wfe and m.wee are contiguous in LDS
 // in the same order.  sp_b: this utterance's sproj row or null.
-__device__ __forceinline__ void e2_tables(const E2Smem &m, const float *__restrict__ sp_b,
-                                          const float *__restrict__ tab, int A, int A16) {
+// The padded tables (W_fe / w_ee, built once per call by e2_prep_kernel) and this step's state
+// projection go global -> registers -> LDS.  Split in two so the caller can put its PH loads in
+// flight BETWEEN the halves: vector loads return in issue order, so the tables (L2 hits, needed
+// first) must be issued before the PH tiles (HBM, needed after the prologue), not behind them.
+struct E2Tab {
+    float4 r[4], s4;
+};
+__device__ __forceinline__ E2Tab e2_tables_load(const float *__restrict__ sp_b, const float *__restrict__ tab,
+                                                int A, int A16) {
     const int tid = threadIdx.x, nt = blockDim.x;
     const int n4 = A16 * 13 / 4;                       // A16 % 16 == 0
-    float4 r[4];
+    E2Tab t;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int f = tid + i * nt;
-        r[i] = ld4(tab + 4 * (f < n4 ? f : 0));
+        t.r[i] = ld4(tab + 4 * (f < n4 ? f : 0));
     }
-    float4 s4 = zero4();
+    t.s4 = zero4();
     const int a4 = tid * 4;
-    if (sp_b != nullptr && a4 < A) s4 = ld4(sp_b + a4);  // A % 4 == 0 on this path
+    if (sp_b != nullptr && a4 < A) t.s4 = ld4(sp_b + a4);  // A % 4 == 0 on this path
+    return t;
+}
+__device__ __forceinline__ void e2_tables_store(const E2Smem &m, const E2Tab &t, const float *__restrict__ sp_b,
+                                                const float *__restrict__ tab, int A, int A16) {
+    const int tid = threadIdx.x, nt = blockDim.x;
+    const int n4 = A16 * 13 / 4;
+    const int a4 = tid * 4;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int f = tid + i * nt;
-        if (f < n4) *reinterpret_cast<float4 *>(m.wfe + 4 * f) = r[i];
+        if (f < n4) *reinterpret_cast<float4 *>(m.wfe + 4 * f) = t.r[i];
     }
     for (int f = tid + 4 * nt; f < n4; f += nt) *reinterpret_cast<float4 *>(m.wfe + 4 * f) = ld4(tab + 4 * f);
-    if (a4 < A16) *reinterpret_cast<float4 *>(m.sp + a4) = s4;
+    if (a4 < A16) *reinterpret_cast<float4 *>(m.sp + a4) = t.s4;
     for (int a = a4 + 4 * nt; a < A16; a += 4 * nt)
         *reinterpret_cast<float4 *>(m.sp + a) = (sp_b != nullptr && a < A) ? ld4(sp_b + a) : zero4();
 }
-
 __device__ __forceinline__ float4 e2_load_ph(const float *__restrict__ PHrow, bool rowok, int a4, int A,
                                              const float *safe) {
     const bool ok = rowok && a4 < A;
@@ -511,12 +524,17 @@ __global__ __launch_bounds__(E2W * 64) void energy_fwd2_kernel(
     const float *PHrow = PH + ((int64_t)b * T + t0 + tl) * A;
     const int MT = A16 / 16, MTP = (MT + E2P - 1) / E2P;
     const int mt0 = part * MTP, mt1 = (dbg & 2) ? mt0 : min(MT, mt0 + MTP);
-    // the PH loads do not depend on the prologue: put them in flight first
+    // table loads first, then the first PH tiles (they do not depend on the prologue), then the
+    // LDS half of the tables
+    const float *sp_b = sp ? sp + (int64_t)b * A : nullptr;
+    const E2Tab tb = e2_tables_load(sp_b, tab, A, A16);
+    __builtin_amdgcn_sched_barrier(0);
     float4 ph[E2PF];
 #pragma unroll
     for (int jx = 0; jx < E2PF; ++jx)
         ph[jx] = e2_load_ph(PHrow, rowok && mt0 + jx < mt1, 16 * (mt0 + jx) + 4 * q, A, PH);
-    e2_tables(m, sp ? sp + (int64_t)b * A : nullptr, tab, A, A16);
+    __builtin_amdgcn_sched_barrier(0);
+    e2_tables_store(m, tb, sp_b, tab, A, A16);
     if (alpha_prev) {
         for (int i = tid; i < TT + KW; i += blockDim.x) {
             const int t = t0 - PADW + i;
@@ -616,15 +634,20 @@ __global__ __launch_bounds__(E2W * 64) void energy_bwd2_kernel(
     const float *PHrow = PH + ((int64_t)b * T + t0 + tl) * A;
     const int MT = A16 / 16, MTP = (MT + E2P - 1) / E2P;
     const int mt0 = prt * MTP, mt1 = min(MT, mt0 + MTP);
-    float4 ph[E2PF];                   // in flight under the prologue
+    // loads in the order their data is needed: <alpha, dalpha> terms and tables (L2), then the
+    // first PH tiles (HBM; in flight under the rest of the prologue)
+    float part = 0.f;
+    for (int t = tid; t < len; t += E2W * 64) part += alpha_s[(int64_t)b * T + t] * dalpha[(int64_t)b * T + t];
+    const E2Tab tb = e2_tables_load(sp + (int64_t)b * A, tab, A, A16);
+    __builtin_amdgcn_sched_barrier(0);
+    float4 ph[E2PF];
 #pragma unroll
     for (int jx = 0; jx < E2PF; ++jx)
         ph[jx] = e2_load_ph(PHrow, rowok && mt0 + jx < mt1, 16 * (mt0 + jx) + 4 * q, A, PH);
-    float part = 0.f;
-    for (int t = tid; t < len; t += E2W * 64) part += alpha_s[(int64_t)b * T + t] * dalpha[(int64_t)b * T + t];
+    __builtin_amdgcn_sched_barrier(0);
     part = wave_sum(part);
     if (lane == 0) m.red[wave] = part;
-    e2_tables(m, sp + (int64_t)b * A, tab, A, A16);
+    e2_tables_store(m, tb, sp + (int64_t)b * A, tab, A, A16);
     for (int i = tid; i < TT * 12; i += blockDim.x) {
         const int r = i / 12, c = i - r * 12;
         m.Fs[i] = (r < nrows && c < NCH) ? Fc_s[((int64_t)b * T + t0 + r) * NCH + c] : 0.f;
