@@ -4,8 +4,8 @@
 
 Imports ``Models.AttModel`` and ``Loss.label_smoothing`` unchanged from
 /root/reference (read-only), seeds torch, and records inputs, every parameter,
-``youtput``, the loss, every parameter gradient, d loss / d x and the greedy
-token sequences.  Only the resulting *data* is committed; no reference code
+``youtput``, the loss, every parameter gradient, d loss / d x and the greedy and
+beam-search token sequences.  Only the resulting *data* is committed; no reference code
 travels.  The reference hard-codes ``.cuda()`` in Loss/label_smoothing.py:18;
 with no GPU in this container ``Tensor.cuda`` is made an identity for the
 duration of the call (the reference file is untouched).
@@ -106,6 +106,19 @@ def run_case(name, spec, AttModel, label_smoothing_loss, frame_stacking):
             res[eos, :len(r)] = r
         out[f"greedy.utt{utt}"] = res
     out["greedy.max_len"] = np.array(hp.max_decoder_seq_len)
+    # beam search (the same Models/decoder.py:63-130 with beam_width > 1): width 3 with the
+    # log_softmax score on utterances 0 and 1, width 2 with the softmax score on utterance 0;
+    # eos swept as above (decode() returns the best hypothesis once it ends in eos, else []).
+    for tag, width, score, utts in (("beam3", 3, "log_softmax", range(min(B, 2))), ("beam2sm", 2, "softmax", (0,))):
+        hp.beam_width, hp.score_func = width, score
+        for utt in utts:
+            res = -np.ones((V, hp.max_decoder_seq_len), dtype=np.int64)
+            for eos in range(V):
+                hp.eos_id = eos
+                r = model.decode(x[utt:utt + 1], lens[utt:utt + 1], None, None)
+                res[eos, :len(r)] = r
+            out[f"{tag}.utt{utt}"] = res
+    hp.beam_width, hp.score_func = 1, "log_softmax"
     return out
 
 

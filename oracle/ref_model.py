@@ -201,6 +201,44 @@ class Decoder(nn.Module):
         return [], seq
 
 
+    @torch.no_grad()
+    def decode_beam(self, hbatch, lengths, beam_width, max_len, eos_id, score_func="log_softmax"):
+        """Models/decoder.py:63-130 with beam_width >= 1 (batch 1, no LM).
+
+        Every live hypothesis is advanced by one attention step, its ``beam_width`` best tokens
+        (repeated argmax, :109-116) become candidates scored ``old score + (log-)probability``
+        (:115; with score_func == 'softmax' the reference adds probabilities), all candidates are
+        sorted by score with a stable sort (:122) and the best ``beam_width`` survive.  The search
+        stops as soon as the best survivor ends in eos (:125-128) and returns that sequence;
+        otherwise [] after ``max_len`` steps.  Returns (result, trace): trace[k] = the survivors of
+        step k as (tokens, score)."""
+        assert hbatch.size(0) == 1
+        T = hbatch.size(1)
+        e_mask = self._mask(hbatch, lengths)
+        beams = [([], 0.0, (hbatch.new_zeros(1, self.hd), hbatch.new_zeros(1, self.hd), hbatch.new_zeros(1, 1, T)))]
+        trace = []
+        for _ in range(max_len):
+            cands = []
+            for seq, score, (c, s, alpha) in beams:
+                g, alpha_n = self.att(s, hbatch, alpha, e_mask)
+                y = self.L_yy(torch.tanh(self.L_gy(g) + self.L_sy(s)))
+                y = F.log_softmax(y, dim=1) if score_func == "log_softmax" else F.softmax(y, dim=1)
+                tmpy = y.clone()
+                for _k in range(beam_width):
+                    best = tmpy.argmax(1)
+                    cand_score = score + float(tmpy[0, best])
+                    tmpy[0, best] = -10000000000.0
+                    rec = self.L_ys(best) + self.L_ss(s) + self.L_gs(g)
+                    s_n, c_n = lstm_cell_tanh_form(rec, c)
+                    cands.append((seq + [int(best)], cand_score, (c_n, s_n, alpha_n)))
+            cands.sort(key=lambda t: t[1], reverse=True)      # stable, like sorted(..., reverse=True)
+            beams = cands[:beam_width]
+            trace.append([(list(b[0]), float(b[1])) for b in beams])
+            if beams[0][0][-1] == eos_id:
+                return list(beams[0][0]), trace
+        return [], trace
+
+
 class AttModel(nn.Module):
     """Models/AttModel.py:10-39, BLSTM branch."""
 
@@ -216,6 +254,9 @@ class AttModel(nn.Module):
     def decode(self, x, lengths, model_lm=None, src_pos=None):
         with torch.no_grad():
             hbatch = self.encoder(x, lengths)
+            if getattr(self.hp, "beam_width", 1) > 1:
+                return self.decoder.decode_beam(hbatch, lengths, self.hp.beam_width, self.hp.max_decoder_seq_len,
+                                                self.hp.eos_id, getattr(self.hp, "score_func", "log_softmax"))[0]
             return self.decoder.decode_greedy(
                 hbatch, lengths, self.hp.max_decoder_seq_len, self.hp.eos_id)[0]
 

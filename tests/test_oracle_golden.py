@@ -86,3 +86,27 @@ def test_greedy_tokens(name):
             got = raw[:raw.index(eos) + 1] if eos in raw else []
             assert got == want, (utt, eos)
         assert greedy_raw_from_table(table) == raw[:len(greedy_raw_from_table(table))]
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_beam_tokens(name):
+    """The oracle's beam search against what the reference's decode() returned (width 3 with
+    the log_softmax score on utterances 0/1, width 2 with the softmax score on utterance 0),
+    for every eos id."""
+    z, hp = load_case(name)
+    m = R.AttModel(hp)
+    m.load_state_dict(params_of(z))
+    m.eval()
+    x = torch.from_numpy(z["x"])
+    lengths = torch.from_numpy(z["lengths"])
+    max_len = int(z["greedy.max_len"])
+    for tag, width, score in (("beam3", 3, "log_softmax"), ("beam2sm", 2, "softmax")):
+        for utt in range(2):
+            if f"{tag}.utt{utt}" not in z.files:
+                continue
+            table = z[f"{tag}.utt{utt}"]
+            hb = m.encoder(x[utt:utt + 1], lengths[utt:utt + 1])
+            for eos in range(hp.num_classes):
+                want = [int(v) for v in table[eos] if v >= 0]
+                got, _ = m.decoder.decode_beam(hb, lengths[utt:utt + 1], width, max_len, eos, score)
+                assert got == want, (tag, utt, eos)
