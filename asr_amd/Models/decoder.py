@@ -201,13 +201,20 @@ class Decoder(nn.Module):
 
     @torch.no_grad()
     def decode(self, hbatch, lengths, model_lm=None):
-        """Greedy search = the beam_width == 1 path of Models/decoder.py:63-130 (batch 1).
+        """Models/decoder.py:63-130 (batch 1, no LM): greedy for ``hp.beam_width == 1``, beam
+        search otherwise.
 
-        Runs the same per-step kernels as training (teacher forcing with the
-        argmax fed back one step at a time).  Returns the token list if the
-        hypothesis ends in ``hp.eos_id`` within ``hp.max_decoder_seq_len`` steps,
-        else ``[]`` -- exactly what the reference returns.
+        Runs the same per-step kernels as training.  Returns the best hypothesis once it ends in
+        ``hp.eos_id`` within ``hp.max_decoder_seq_len`` steps, else ``[]`` -- exactly what the
+        reference returns.
         """
+        if model_lm is not None:
+            raise NotImplementedError("asr_amd.Decoder.decode: LM shallow fusion is outside the path")
+        width = int(getattr(self.hp, "beam_width", 1))
+        if width > 1:
+            from .beam import beam_decode
+            return beam_decode(self, hbatch, lengths, width, self.hp.max_decoder_seq_len, self.hp.eos_id,
+                               getattr(self.hp, "score_func", "log_softmax"))[0]
         return self.decode_raw(hbatch, lengths)[0]
 
     @torch.no_grad()

@@ -92,6 +92,8 @@ SYMBOLS = {
     "asr_attdec_ws_floats": (c_i64, [C.c_int] * 5),
     "asr_attdec_fwd": (C.c_int, [C.POINTER(AttDecFwdArgs), c_f]),
     "asr_attdec_greedy": (C.c_int, [C.POINTER(AttDecFwdArgs), c_f, c_f, c_f, c_f, c_f, c_f, c_f]),
+    "asr_attdec_step_att": (C.c_int, [C.POINTER(AttDecFwdArgs), c_f, c_f]),
+    "asr_attdec_step_cell": (C.c_int, [C.POINTER(AttDecFwdArgs), c_f]),
     "asr_attdec_bwd_ws_floats": (c_i64, [C.c_int] * 5),
     "asr_attdec_bwd": (C.c_int, [C.POINTER(AttDecBwdArgs), c_f]),
 }

@@ -809,6 +809,76 @@ static int run_attdec_fwd(const asr_attdec_fwd_args *a, const GreedyParams *gp, 
     return ASR_OK;
 }
 
+// ------------------------------------------------ single steps (beam search) --
+// The two halves of one decoder step for callers that choose the fed-back token themselves
+// (beam search, Models/decoder.py:79-123): attention + context from a given state and previous
+// alignment, then -- after the caller has picked tokens -- the recurrent cell.  Same kernels as
+// the training forward; a is read as one step (L = 1): S, C = state in ([B][Hd]), S + B*Hd,
+// C + B*Hd = state out, alpha/sproj/g/gates/Fc = this step's slabs.
+extern "C" int asr_attdec_step_att(const asr_attdec_fwd_args *a, const float *alpha_prev, void *stream) {
+    ASR_CHECK_ARG(a != nullptr, "attdec_step_att: null args");
+    const int B = a->B, T = a->T, E = a->E, Hd = a->Hd, A = 2 * Hd;
+    ASR_CHECK_ARG(B > 0 && T > 0 && E > 0 && Hd > 0, "attdec_step_att: bad shape");
+    ASR_CHECK_ARG(a->hbatch && a->PH && a->lengths && a->W_se && a->w_ee && a->W_fe && a->conv_w && a->S &&
+                      a->alpha && a->sproj && a->g && a->Fc && a->ws,
+                  "attdec_step_att: null pointer");
+    hipStream_t st = (hipStream_t)stream;
+    const size_t esm = energy_fwd_smem(A);
+    ASR_CHECK_ARG(esm <= 160 * 1024 && (size_t)T * 4 <= 128 * 1024, "attdec_step_att: T=%d / A=%d exceed the LDS budget", T, A);
+    static thread_local bool attr_set = false;
+    if (!attr_set) {
+        ASR_CHECK_HIP(hipFuncSetAttribute((const void *)energy_fwd_kernel,
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));
+        ASR_CHECK_HIP(hipFuncSetAttribute((const void *)ctx_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                          128 * 1024));
+        ASR_CHECK_HIP(hipFuncSetAttribute((const void *)energy_fwd2_kernel,
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+        attr_set = true;
+    }
+    const int64_t BT = (int64_t)B * T;
+    const int A16p = (A + 15) & ~15;
+    float *e_buf = a->ws;
+    float *tab = a->ws + BT + 64;
+    const int vecPH = al16(a->PH) && A % 4 == 0;
+    const size_t esm2 = energy_fwd2_smem(A);
+    const bool use_v2 = vecPH && esm2 <= 150 * 1024;
+    const int vecH = al16(a->hbatch) && E % 4 == 0;
+    const int vecS = al16(a->S) && al16(a->W_se) && Hd % 4 == 0;
+    // W_se s: with the all-zero initial state this is zero, as in the first training step
+    hipLaunchKernelGGL(sproj_kernel, dim3(cdiv(A, 16), cdiv(B, 16)), dim3(256), 0, st, (const float *)a->S, a->W_se,
+                       a->sproj, B, Hd, A, vecS);
+    if (use_v2) {
+        hipLaunchKernelGGL(e2_prep_kernel, dim3(cdiv((int64_t)A16p * 12, 256)), dim3(256), 0, st, a->w_ee, a->W_fe,
+                           A, A16p, tab);
+        hipLaunchKernelGGL(energy_fwd2_kernel, dim3(cdiv(T, TT), B), dim3(E2W * 64), esm2, st, a->PH, alpha_prev,
+                           (const float *)a->sproj, (const float *)tab, a->conv_w, a->lengths, e_buf, a->Fc, T, A, 0);
+    } else {
+        hipLaunchKernelGGL(energy_fwd_kernel, dim3(cdiv(T, TT), B), dim3(EW * 64), esm, st, a->PH, alpha_prev,
+                           (const float *)a->sproj, a->w_ee, a->W_fe, a->conv_w, a->lengths, e_buf, a->Fc, T, A,
+                           vecPH);
+    }
+    hipLaunchKernelGGL(ctx_kernel, dim3(cdiv(E, 64), B), dim3(256), sizeof(float) * T, st, e_buf, a->hbatch,
+                       a->lengths, a->alpha, a->g, T, E, vecH);
+    ASR_CHECK_LAUNCH("attdec_step_att kernels");
+    return ASR_OK;
+}
+
+extern "C" int asr_attdec_step_cell(const asr_attdec_fwd_args *a, void *stream) {
+    ASR_CHECK_ARG(a != nullptr, "attdec_step_cell: null args");
+    const int B = a->B, E = a->E, Hd = a->Hd, V = a->V;
+    ASR_CHECK_ARG(B > 0 && E > 0 && Hd > 0 && V > 0, "attdec_step_cell: bad shape");
+    ASR_CHECK_ARG(a->targets && a->Emb && a->W_ss && a->W_gs && a->b_gs && a->S && a->C && a->g && a->gates,
+                  "attdec_step_cell: null pointer");
+    const int64_t BH = (int64_t)B * Hd;
+    const int vecS = al16(a->S) && al16(a->W_ss) && Hd % 4 == 0;
+    const int vecG = al16(a->g) && al16(a->W_gs) && E % 4 == 0;
+    hipLaunchKernelGGL(cell_fwd_kernel, dim3(cdiv(Hd, 4), cdiv(B, 16)), dim3(256), 0, (hipStream_t)stream,
+                       (const float *)a->S, (const float *)a->C, (const float *)a->g, a->targets, 0, 1, V, a->Emb,
+                       a->W_ss, a->W_gs, a->b_gs, a->gates, a->S + BH, a->C + BH, B, Hd, E, vecS, vecG);
+    ASR_CHECK_LAUNCH("cell_fwd_kernel");
+    return ASR_OK;
+}
+
 extern "C" int asr_attdec_fwd(const asr_attdec_fwd_args *a, void *stream) {
     return run_attdec_fwd(a, nullptr, stream);
 }

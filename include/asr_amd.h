@@ -254,6 +254,16 @@ int asr_attdec_fwd(const asr_attdec_fwd_args *a, void *stream);
 int asr_attdec_greedy(const asr_attdec_fwd_args *a, const float *W_sy, const float *W_gy,
                       const float *b_gy, const float *W_yy, const float *b_yy, int64_t *tokens,
                       void *stream);
+/* One decoder step in two halves, for callers that choose the fed-back token themselves: the
+ * beam search of Models/decoder.py:79-123.  `a` is read as a single step (L ignored):
+ *   asr_attdec_step_att : attention + context (Models/attention.py:24-40) from the state a->S
+ *       ([B][Hd]) and the previous alignment alpha_prev ([B][T], NULL = zeros: first step) ->
+ *       a->alpha [B][T], a->g [B][E]  (a->sproj, a->Fc, a->ws are scratch of one step's size)
+ *   asr_attdec_step_cell: rec = Emb[targets[b]] + L_ss s + L_gs g, LSTM cell
+ *       (Models/decoder.py:118-119,269-279): a->S, a->C in -> a->S + B*Hd, a->C + B*Hd out
+ *       (targets: [B] int64, a->gates [B][4Hd] scratch). */
+int asr_attdec_step_att(const asr_attdec_fwd_args *a, const float *alpha_prev, void *stream);
+int asr_attdec_step_cell(const asr_attdec_fwd_args *a, void *stream);
 
 typedef struct {
     asr_attdec_fwd_args f;    /* same tensors as the forward call */
