@@ -143,7 +143,7 @@ def roofline_probe(hp, dev):
     flops = 2.0 * M * N * K
     out["sgemm_proj"] = {"bound": "mfma", "achieved": flops / dt / 1e12, "peak": MFMA_F32_PEAK_TFLOPS,
                          "unit": "TFLOP/s", "frac": flops / dt / 1e12 / MFMA_F32_PEAK_TFLOPS, "traffic": None,
-                         "kernel": "sgemm_kernel<128,64,16,0,0,true>", "shape": [M, N, K], "avg_us": dt * 1e6}
+                         "kernel": "sgemm_kernel<128,64,32,0,0,true>", "shape": [M, N, K], "avg_us": dt * 1e6}
     # (3) fused label-smoothed CE: logits read once + gradient written once
     Bq, L, V = 32, 100, hp.num_classes
     z = torch.randn(Bq, L, V, generator=g).to(dev)
