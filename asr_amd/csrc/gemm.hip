@@ -327,6 +327,10 @@ extern "C" int asr_sgemm(const asr_gemm_desc *din, void *stream) {
         dim3 grid(cdiv(d.N, 64), cdiv(d.M, 128), d.nbatch * splitk);
         ASR_CHECK_ARG(grid.y <= 65535 && grid.z <= 65535, "sgemm: grid too large");
         if (GK == 32) { LAUNCH_MODES(128, 64, 32, true) } else { LAUNCH_MODES(128, 64, 16, true) }
+    } else if (big && fast && tile_cfg == 3) {   // experiment: 64 x 64 tiles (short workgroups)
+        dim3 grid(cdiv(d.N, 64), cdiv(d.M, 64), d.nbatch * splitk);
+        ASR_CHECK_ARG(grid.y <= 65535 && grid.z <= 65535, "sgemm: grid too large");
+        if (GK == 32) { LAUNCH_MODES(64, 64, 32, true) } else { LAUNCH_MODES(64, 64, 16, true) }
     } else if (big) {
         dim3 grid(cdiv(d.N, 128), cdiv(d.M, 128), d.nbatch * splitk);
         ASR_CHECK_ARG(grid.y <= 65535 && grid.z <= 65535, "sgemm: grid too large");

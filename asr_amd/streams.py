@@ -10,7 +10,6 @@ for the side stream, so every ``.grad`` is complete when ``backward()`` returns 
 to the caller's stream.
 """
 import os
-import threading
 
 import torch
 
@@ -28,7 +27,6 @@ def enable(flag=True):
 
 
 _streams = {}
-_tls = threading.local()
 
 
 def side_stream(device):
@@ -57,17 +55,13 @@ def pipe_stream(device):
     return s
 
 
-def _join(device):
-    torch.cuda.current_stream(device).wait_stream(side_stream(device))
-    _tls.armed = False
-
-
-def arm_join(device):
-    """Queue (once per backward pass) the callback that joins the side stream."""
-    if getattr(_tls, "armed", False):
-        return
-    _tls.armed = True
-    torch.autograd.Variable._execution_engine.queue_callback(lambda: _join(device))
+def arm_join(device, main):
+    """Queue the end-of-backward callback that makes `main` -- the stream this backward node runs
+    on, captured now: the callback itself may run on another thread with another current stream --
+    wait for the side stream.  Queued by every block (a few redundant event waits per pass) rather
+    than once per pass: no cross-thread bookkeeping about which pass is running."""
+    side = side_stream(device)
+    torch.autograd.Variable._execution_engine.queue_callback(lambda: main.wait_stream(side))
 
 
 def wait_side(device):
@@ -94,13 +88,14 @@ class on_side:
         if not ENABLED or any(p.grad is not None for p in self.params):
             return self
         side = side_stream(self.device)
+        main = torch.cuda.current_stream(self.device)
         ev = torch.cuda.Event()
-        ev.record(torch.cuda.current_stream(self.device))
+        ev.record(main)
         side.wait_event(ev)
         for t in self.tensors:
             if t is not None:
                 t.record_stream(side)
-        arm_join(self.device)
+        arm_join(self.device, main)
         self.ctx = torch.cuda.stream(side)
         self.ctx.__enter__()
         return self

@@ -326,6 +326,36 @@ def test_golden_forward_backward_with_side_stream(name):
         streams.enable(False)
 
 
+def test_side_stream_join_on_a_user_stream():
+    """Forward/backward issued on a non-default stream with the side-stream overlap on: the
+    end-of-backward join must make THAT stream wait for the weight gradients."""
+    from asr_amd import streams
+    from asr_amd.Loss.label_smoothing import label_smoothing_loss
+    z, hp = load_case("mixed_h")
+    dev = _dev()
+    m = _build(hp, params_of(z))
+    lengths = torch.from_numpy(z["lengths"])
+    targets = torch.from_numpy(z["targets"]).to(dev)
+    tl = torch.from_numpy(z["text_lengths"]).to(dev)
+    x = torch.from_numpy(z["x"]).to(dev)
+    user = torch.cuda.Stream()
+    torch.cuda.synchronize()
+    streams.enable(True)
+    try:
+        with torch.cuda.stream(user):
+            for _ in range(3):
+                for p in m.parameters():
+                    p.grad = None
+                loss = label_smoothing_loss(m(x, lengths, targets), targets, tl, hp.T_norm, hp.B_norm)
+                loss.backward()
+            grads = {k: p.grad.clone() for k, p in m.named_parameters()}   # reads on `user`, no device sync before
+        user.synchronize()
+        for k, g in grads.items():
+            assert rel_err(g.cpu(), z[f"f64.grad.{k}"]) < GRAD_TOL, k
+    finally:
+        streams.enable(False)
+
+
 @pytest.mark.parametrize("name", CASES)
 def test_golden_greedy_tokens(name):
     z, hp = load_case(name)
