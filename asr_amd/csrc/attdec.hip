@@ -1506,16 +1506,6 @@ __global__ __launch_bounds__(256) void phase2_mfma_kernel(
     }
 }
 
-// out[i] = sum_p part[p*n + i]
-__global__ __launch_bounds__(256) void reduce_parts_kernel(const float *__restrict__ part, int nparts,
-                                                           int64_t n, float *__restrict__ out) {
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    float s = 0.f;
-    for (int p = 0; p < nparts; ++p) s += part[(int64_t)p * n + i];
-    out[i] = s;
-}
-
 // split [A][11] sums into dw_ee[A] and dW_fe[A][10]
 __global__ __launch_bounds__(256) void split_fe_kernel(const float *__restrict__ sum11, int A,
                                                        float *__restrict__ dw_ee, float *__restrict__ dW_fe) {
