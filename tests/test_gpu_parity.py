@@ -120,7 +120,9 @@ def test_loss_kernel_vs_oracle(B, L, V, T_norm, B_norm):
 
 # ------------------------------------------------------ encoder / decoder --
 @pytest.mark.parametrize("B,T,D,H,N,lens", [(3, 17, 12, 8, 2, [17, 9, 4]), (5, 33, 6, 12, 1, [20, 33, 1, 33, 7]),
-                                            (18, 21, 10, 32, 3, None), (2, 40, 240, 320, 2, [40, 31])])
+                                            (18, 21, 10, 32, 3, None), (2, 40, 240, 320, 2, [40, 31]),
+                                            (35, 9, 5, 8, 1, None), (2, 1, 4, 8, 2, [1, 1]),
+                                            (33, 12, 6, 64, 2, None)])
 def test_blstm_vs_oracle(B, T, D, H, N, lens):
     from asr_amd.Models.encoder import Encoder
     from oracle import ref_model as R
@@ -238,7 +240,8 @@ def test_chunk_pipelined_encoder_matches_whole_layer_launches(H, B, T, chunks, p
 
 @pytest.mark.parametrize("B,T,He,Hd,V,L,lens", [(3, 17, 8, 8, 11, 5, [17, 9, 4]), (4, 70, 6, 10, 13, 6, [70, 64, 65, 1]),
                                                 (2, 130, 16, 320, 50, 4, [130, 77]), (17, 150, 12, 16, 9, 3, None),
-                                                (3, 40, 5, 9, 7, 4, [40, 22, 7])])
+                                                (3, 40, 5, 9, 7, 4, [40, 22, 7]), (2, 3, 4, 8, 5, 1, [3, 1]),
+                                                (34, 20, 4, 8, 6, 2, None)])
 def test_decoder_vs_oracle(B, T, He, Hd, V, L, lens):
     from asr_amd.Models.decoder import Decoder
     from oracle import ref_model as R
@@ -264,7 +267,9 @@ def test_decoder_vs_oracle(B, T, He, Hd, V, L, lens):
     assert rel_err(yd.detach().cpu(), yr.detach()) < OUT_TOL
     assert rel_err(hd.grad.cpu(), hr.grad) < GRAD_TOL
     for (k, p), (_, q) in zip(dec.named_parameters(), ref.named_parameters()):
-        assert rel_err(p.grad.cpu(), q.grad) < GRAD_TOL, k
+        # a parameter the reference never touched (L == 1) has no gradient there, zeros here
+        qg = q.grad if q.grad is not None else torch.zeros_like(q)
+        assert rel_err(p.grad.cpu(), qg) < GRAD_TOL, k
 
 
 # ------------------------------------------------- golden vectors (reference) --
