@@ -134,6 +134,20 @@ def roofline_probe(hp, dev):
                         "kernel": "blstm_fwd_persist_kernel<1,2,5>", "shape": [T, B, H], "avg_us": dt * 1e6,
                         "us_per_time_step": dt * 1e6 / T,
                         "note": "latency-bound recurrence: 500 dependent steps per launch"}
+    # (1b) its backward: dG[t] = f(dH[t] + dG[t+1] W_hh, saved gates), same T x 2 x (B x 4H) @ (4H x H) chain
+    WT = W.transpose(1, 2).contiguous()
+    dH = torch.randn(T, B, 2 * H, generator=g).to(dev)
+    dc = torch.empty(2 * B * H, device=dev)
+
+    def lstm_bwd():
+        lib.asr_blstm_bwd(W.data_ptr(), WT.data_ptr(), Gw.data_ptr(), Cs.data_ptr(), dH.data_ptr(), B * 2 * H, 2 * H,
+                          lengths.data_ptr(), dc.data_ptr(), T, B, H, ws.data_ptr(), st)
+    dt = time_kernel_events(lstm_bwd, 5)
+    out["blstm_bwd"] = {"bound": "mfma", "achieved": flops / dt / 1e12, "peak": MFMA_F32_PEAK_TFLOPS,
+                        "unit": "TFLOP/s", "frac": flops / dt / 1e12 / MFMA_F32_PEAK_TFLOPS, "traffic": None,
+                        "kernel": "blstm_bwd_rs_kernel<8,5>", "shape": [T, B, H], "avg_us": dt * 1e6,
+                        "us_per_time_step": dt * 1e6 / T,
+                        "note": "timed alone; in the step the side stream's weight-gradient GEMMs share its CUs"}
     # (2) input-projection GEMM of an upper encoder layer: (T*B x 2H) @ (2H x 4H), fp32 MFMA
     M, N, K = T * B, 4 * H, 2 * H
     A = torch.randn(M, K, generator=g).to(dev)
