@@ -34,9 +34,9 @@ class AttModel(nn.Module):
 
     def forward(self, x, lengths, targets, src_pos=None):
         # one asynchronous host -> device hand-over of the lengths for both halves of the model
-        lengths = lengths_to_device(lengths, x.device)
-        hbatch = self.encoder(x, lengths)
-        return self.decoder(hbatch, lengths, targets)
+        lengths_dev = lengths_to_device(lengths, x.device)
+        hbatch = self.encoder(x, lengths_dev, lengths_host=None if lengths.is_cuda else lengths)
+        return self.decoder(hbatch, lengths_dev, targets)
 
     def decode(self, x, lengths, model_lm=None, src_pos=None):
         if model_lm is not None:

@@ -4,8 +4,10 @@ Same constructor arguments (read from ``hp``), same parameter names
 (``bi_lstm.weight_ih_l0`` ... ``bi_lstm.bias_hh_l4_reverse``), same
 ``forward(x, lengths) -> hbatch (B,T,2H)`` contract: every sequence runs over
 its own ``lengths[b]`` frames in both directions, rows past the length are 0.
-No packing: the recurrence kernels mask by length (asr_blstm_fwd/bwd), the
-input projections of all frames are MFMA GEMMs (asr_sgemm).
+No packed copies: the recurrence kernels mask by length (asr_blstm_fwd/bwd); the
+input projections and their gradients are MFMA GEMMs (asr_sgemm) that run over a
+row list of the frames inside their sequences, so padded frames cost no matrix
+work -- what pack_padded_sequence (Models/encoder.py:32) buys the reference.
 """
 import ctypes as C
 import math
@@ -92,6 +94,40 @@ PIPE_FWD = os.environ.get("ASR_PIPE_FWD", "1") != "0"
 PIPE_BWD = os.environ.get("ASR_PIPE_BWD", "1") != "0"
 
 
+# Row lists: when at least this share of the (T x B) frames is padding, the layer GEMMs skip it.
+ROW_LIST_MIN_PADDING = float(os.environ.get("ASR_ROW_LIST_MIN_PADDING", "0.04"))
+
+
+class _RowLists:
+    """Device lists (int32) of the frames t*B + b that lie inside their sequence, t-major:
+    rows    -- all of them (n entries): input projections, dX, dW_ih;
+    prev    -- (t-1)*B + b for the listed frames with t >= 1 (n_prev entries): the forward
+               direction's dW_hh pairs dG[t] with h[t-1];
+    rows[:n_next] -- the listed frames with t <= T-2: the reverse direction pairs dG[t], h[t+1]."""
+
+    def __init__(self, rows, n, prev, n_prev, n_next):
+        self.rows, self.n, self.prev, self.n_prev, self.n_next = rows, n, prev, n_prev, n_next
+
+
+def _row_lists(lengths, T, B, dev):
+    """None when the lengths live on the device already (building the lists would stall the host),
+    or when the batch has too little padding for them to pay."""
+    if lengths.is_cuda or T * B == 0:
+        return None
+    ln = lengths.detach().to(torch.int64).clamp(0, T)
+    n = int(ln.sum())
+    if n == 0 or n > (1.0 - ROW_LIST_MIN_PADDING) * T * B:
+        return None
+    mask = torch.arange(T).unsqueeze(1) < ln.unsqueeze(0)             # (T, B)
+    rows = torch.nonzero(mask.flatten()).flatten().to(torch.int32)
+    nb0, nbl = int(mask[0].sum()), int(mask[T - 1].sum())
+    staged = torch.empty(2 * n - nb0, dtype=torch.int32, pin_memory=True)
+    staged[:n] = rows
+    staged[n:] = rows[nb0:] - B
+    both = staged.to(dev, non_blocking=True)
+    return _RowLists(both[:n], n, both[n:], n - nb0, n - nbl)
+
+
 def _chunks(T, n):
     tc = -(-T // n)
     return [(s0, min(T, s0 + tc)) for s0 in range(0, T, tc)]
@@ -121,8 +157,8 @@ class _BLSTMLayerFunction(torch.autograd.Function):
     nxt: _Next to fill for the layer above (the output is then already dropped out) or None."""
 
     @staticmethod
-    def forward(ctx, inp, lengths_dev, first, last, H, pre, nxt, w_ih_f, w_hh_f, b_ih_f, b_hh_f, w_ih_r, w_hh_r,
-                b_ih_r, b_hh_r):
+    def forward(ctx, inp, lengths_dev, rl, first, last, H, pre, nxt, w_ih_f, w_hh_f, b_ih_f, b_hh_f, w_ih_r,
+                w_hh_r, b_ih_r, b_hh_r):
         lib = _lib.load()
         inp = inp.contiguous()
         if first:
@@ -138,10 +174,13 @@ class _BLSTMLayerFunction(torch.autograd.Function):
         if pre is not None and pre.G is not None:
             G, pre.G = pre.G, None
         else:
+            # padded frames of G stay unwritten: the recurrence kernel never uses them and
+            # overwrites them with the zeros its backward expects
             G = torch.empty(T, B, 2, 4 * H, **f32)
+            rows, nrows = (rl.rows, rl.n) if rl is not None else (None, T * B)
             for d, (w_ih, b_ih, b_hh) in enumerate(((w_ih_f, b_ih_f, b_hh_f), (w_ih_r, b_ih_r, b_hh_r))):
-                ops.sgemm(inp, w_ih, G, T * B, 4 * H, D, a_two=in_two, b_stride=D, c_stride=8 * H,
-                          c_off=d * 4 * H, bias1=b_ih, bias2=b_hh)
+                ops.sgemm(inp, w_ih, G, nrows, 4 * H, D, a_two=in_two, b_stride=D, c_stride=8 * H,
+                          c_off=d * 4 * H, bias1=b_ih, bias2=b_hh, m_idx=rows)
         W_hh = torch.cat([w_hh_f, w_hh_r], 0)      # [2][4H][H]
         if last:
             Hout = torch.empty(B, T, 2 * H, **f32)
@@ -196,6 +235,7 @@ class _BLSTMLayerFunction(torch.autograd.Function):
         ctx.wparams = (w_ih_f, w_hh_f, b_ih_f, b_hh_f, w_ih_r, w_hh_r, b_ih_r, b_hh_r)
         ctx.p = nxt.p if mask is not None else 0.0
         ctx.dims = (B, T, D, H, first, in_two, ho_t, ho_b)
+        ctx.rl = rl
         return out
 
     @staticmethod
@@ -203,6 +243,7 @@ class _BLSTMLayerFunction(torch.autograd.Function):
         lib = _lib.load()
         B, T, D, H, first, in_two, ho_t, ho_b = ctx.dims
         inp, G, Cs, Hout, lengths_dev, w_ih_f, w_hh_f, w_ih_r, w_hh_r = ctx.saved_tensors
+        rl = ctx.rl
         dev = inp.device
         st = _stream()
         dOut = dOut.contiguous()                   # same layout as Hout
@@ -228,10 +269,13 @@ class _BLSTMLayerFunction(torch.autograd.Function):
             # critical path first: the input gradient feeds the next layer's recurrence
             if need_dx:
                 # dX = dG[:, fwd] W_ih_f + dG[:, rev] W_ih_r, written in the input's own layout
-                dIn = torch.empty_like(inp)
+                # with a row list the padded frames of dX are not written: the layer below never
+                # reads them (its recurrence masks by length); the caller of the first layer might
+                rows, nrows = (rl.rows, rl.n) if rl is not None else (None, T * B)
+                dIn = torch.zeros_like(inp) if (first and rl is not None) else torch.empty_like(inp)
                 for d, w_ih in enumerate((w_ih_f, w_ih_r)):
-                    ops.sgemm(dG, w_ih, dIn, T * B, D, 4 * H, a_stride=8 * H, a_off=d * 4 * H, b_mode=1,
-                              b_stride=D, c_two=in_two, accumulate=(d == 1))
+                    ops.sgemm(dG, w_ih, dIn, nrows, D, 4 * H, a_stride=8 * H, a_off=d * 4 * H, b_mode=1,
+                              b_stride=D, c_two=in_two, accumulate=(d == 1), m_idx=rows)
         else:
             # time-major input (T,B,D): the rows of a frame range are contiguous in dG and dX
             dIn = torch.empty_like(inp)
@@ -258,34 +302,39 @@ class _BLSTMLayerFunction(torch.autograd.Function):
         # next layer's (latency-bound) recurrence kernel
         hout_two = (B, ho_b, ho_t)                 # row (t*B + b) <-> Hout element offset
         grads = {}
-        with streams.on_side(dev, G, inp, Hout, params=ctx.wparams):
+        side_reads = (G, inp, Hout) + ((rl.rows,) if rl is not None else ())    # rows and prev share a block
+        with streams.on_side(dev, *side_reads, params=ctx.wparams):
             db = torch.empty(8 * H, **f32)
             ops.colsum(dG, db)                     # b_ih and b_hh receive the same column sums
             for d in range(2):
                 # dW_hh[d] = sum_t dG_t^T h_{t-1}: forward pairs (t, t-1), reverse pairs (t, t+1);
                 # padded rows of dG and Hout are zero, so ragged lengths need no masking here
+                # (the row lists only skip their work)
                 gW = torch.empty(4 * H, H, **f32)
                 if T > 1:
                     K = (T - 1) * B
+                    kl = None
+                    if rl is not None:
+                        kl, K = (rl.prev, rl.n_prev) if d == 0 else (rl.rows, rl.n_next)
                     sk = ops.pick_splitk(4 * H, H, K)
                     if sk > 1:
                         gW.zero_()
                     a_off = d * 4 * H + (B * 8 * H if d == 0 else 0)
                     b_off = d * H + (0 if d == 0 else ho_t)
                     ops.sgemm(dG, Hout, gW, 4 * H, H, K, a_mode=1, a_stride=8 * H, a_off=a_off, b_mode=1,
-                              b_two=hout_two, b_off=b_off, c_stride=H, splitk=sk)
+                              b_two=hout_two, b_off=b_off, c_stride=H, splitk=sk, k_idx=kl)
                 else:
                     gW.zero_()
                 # dW_ih[d] = dG[:, d]^T X
                 gWi = torch.empty(4 * H, D, **f32)
-                K = T * B
+                kl, K = (rl.rows, rl.n) if rl is not None else (None, T * B)
                 sk = ops.pick_splitk(4 * H, D, K)
                 if sk > 1:
                     gWi.zero_()
                 ops.sgemm(dG, inp, gWi, 4 * H, D, K, a_mode=1, a_stride=8 * H, a_off=d * 4 * H, b_mode=1,
-                          b_two=in_two, c_stride=D, splitk=sk)
+                          b_two=in_two, c_stride=D, splitk=sk, k_idx=kl)
                 grads[d] = (gWi, gW, db[d * 4 * H:(d + 1) * 4 * H], db[d * 4 * H:(d + 1) * 4 * H].clone())
-        return (dIn, None, None, None, None, None, None) + grads[0] + grads[1]
+        return (dIn, None, None, None, None, None, None, None) + grads[0] + grads[1]
 
 
 class _DropoutFunction(torch.autograd.Function):
@@ -322,10 +371,13 @@ class Encoder(nn.Module):
         self.bi_lstm = BiLSTMParams(hp.lmfb_dim * hp.frame_stacking, self.hidden, self.num_layers)
         self._step = 0
 
-    def forward(self, x, lengths):
+    def forward(self, x, lengths, lengths_host=None):
+        """lengths_host: the same lengths on the CPU when `lengths` was moved to the device already
+        (AttModel does that once for both halves); lets the GEMMs skip the padded frames."""
         if not x.is_cuda:
             raise RuntimeError("asr_amd.Encoder: input must be on the GPU; the HIP path has no CPU fallback")
         lengths_dev = lengths_to_device(lengths, x.device)
+        rl = _row_lists(lengths if lengths_host is None else lengths_host, x.shape[1], x.shape[0], x.device)
         p = self.dropout if self.training else 0.0
         seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if p > 0.0 else 0
         h = x.float()
@@ -339,7 +391,7 @@ class Encoder(nn.Module):
             if pipelined and not last:
                 n = flat[8 * (layer + 1): 8 * (layer + 1) + 8]     # (w_ih, w_hh, b_ih, b_hh) x (fwd, rev)
                 nxt = _Next(n[0], n[2], n[3], n[4], n[6], n[7], p, seed + 7919 * layer)
-            h = _BLSTMLayerFunction.apply(h, lengths_dev, layer == 0, last, self.hidden, pre, nxt,
+            h = _BLSTMLayerFunction.apply(h, lengths_dev, rl, layer == 0, last, self.hidden, pre, nxt,
                                           *flat[8 * layer: 8 * layer + 8])
             if nxt is None and p > 0.0 and not last:
                 h = _DropoutFunction.apply(h, p, seed + 7919 * layer)

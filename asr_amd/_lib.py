@@ -29,6 +29,7 @@ class GemmDesc(C.Structure):
         ("splitk", C.c_int),
         ("nbatch", C.c_int),
         ("batch_a", c_i64), ("batch_b", c_i64), ("batch_c", c_i64),
+        ("m_idx", c_f), ("k_idx", c_f),
     ]
 
 

@@ -40,7 +40,7 @@ __device__ __forceinline__ int64_t view_rowoff(const OperandView &v, int i) {
 // Per-thread slots of a (R x GK) operand tile, R/64 float4s each.
 //   mode 0: element (r,k) at p[rowoff(r0+r) + k];   slot f -> r = f>>2, k4 = f&3   (row fixed per slot)
 //   mode 1: element (r,k) at p[rowoff(k) + r0+r];   slot f -> k = f/(R/4), r4 = f%(R/4)
-template <int R, int GK, int MODE, bool FAST>
+template <int R, int GK, int MODE, bool FAST, bool KLIST = false>
 struct TileLoader {
     static constexpr int NS = R * GK / 1024;   // float4 slots per thread
     static constexpr int KQ = GK / 4;          // float4s per row (mode 0)
@@ -48,6 +48,7 @@ struct TileLoader {
     int rk[NS];              // mode 0: k offset inside the tile; mode 1: k row inside the tile
     int rcol[NS];            // mode 1: first column of the float4
     unsigned okmask[NS];     // FAST: all-ones if the slot of the tile in flight is in range
+    int kx[NS];              // KLIST: the row-list entry of this slot for the tile loaded next
 
     __device__ __forceinline__ void apply_mask(float4 (&regs)[NS]) const {
         if (!FAST) return;
@@ -61,14 +62,15 @@ struct TileLoader {
         }
     }
 
-    __device__ __forceinline__ void init(const OperandView &v, int r0, int rmax) {
+    // midx (mode 0): list entry r names the operand's row
+    __device__ __forceinline__ void init(const OperandView &v, int r0, int rmax, const int32_t *midx) {
         const int tid = threadIdx.x;
 #pragma unroll
         for (int i = 0; i < NS; ++i) {
             const int f = tid + 256 * i;
             if (MODE == 0) {
                 const int r = r0 + f / KQ;
-                base[i] = r < rmax ? v.p + view_rowoff(v, r) : nullptr;
+                base[i] = r < rmax ? v.p + view_rowoff(v, midx ? midx[r] : r) : nullptr;
                 rk[i] = (f % KQ) * 4;
                 rcol[i] = 0;
             } else {
@@ -80,17 +82,26 @@ struct TileLoader {
         }
     }
 
+    // KLIST: the list entries are fetched one k-tile ahead of the rows they name, so the row
+    // loads never wait behind an index load
+    __device__ __forceinline__ void init_klist(const int32_t *kidx, int k0, int klast) {
+        if (!KLIST) return;
+#pragma unroll
+        for (int i = 0; i < NS; ++i) kx[i] = kidx[min(k0 + rk[i], klast)];
+    }
+
     // FAST: every float4 that starts in bounds lies fully in bounds and is 16-byte
     // aligned (host-checked), so the loads are unconditional (out-of-range slots read a
     // safe address and are masked to zero): no branches, all loads of a tile in flight.
     __device__ __forceinline__ void load(const OperandView &v, int rmax, int k0, int kend, bool vec,
-                                         float4 (&regs)[NS]) {
+                                         float4 (&regs)[NS], const int32_t *kidx = nullptr, int klast = 0) {
 #pragma unroll
         for (int i = 0; i < NS; ++i) {
             const int k = k0 + rk[i];
+            const int krow = KLIST ? kx[i] : k;      // mode 1: the operand row that holds index k
             if (FAST) {
                 const bool ok = base[i] != nullptr && k < kend;
-                const float *src = MODE == 0 ? base[i] + k : base[i] + view_rowoff(v, k);
+                const float *src = MODE == 0 ? base[i] + k : base[i] + view_rowoff(v, krow);
                 src = ok ? src : v.p;
                 regs[i] = ld4(src);      // masked to zero later, in apply_mask (after the MFMAs)
                 okmask[i] = ok ? 0xffffffffu : 0u;
@@ -109,7 +120,7 @@ struct TileLoader {
                         if (k + 3 < kend) out.w = src[3];
                     }
                 } else {
-                    const float *src = base[i] + view_rowoff(v, k);
+                    const float *src = base[i] + view_rowoff(v, krow);
                     const int r = rcol[i];
                     if (vec && r + 3 < rmax) {
                         out = ld4(src);
@@ -122,6 +133,10 @@ struct TileLoader {
                 }
             }
             regs[i] = out;
+        }
+        if (KLIST) {
+#pragma unroll
+            for (int i = 0; i < NS; ++i) kx[i] = kidx[min(k0 + GK + rk[i], klast)];
         }
     }
 };
@@ -145,7 +160,7 @@ __device__ __forceinline__ void store_tile(float (*lds)[R + GPAD(MODE)], const f
     }
 }
 
-template <int BM, int BN, int GK, int AMODE, int BMODE, bool FAST>
+template <int BM, int BN, int GK, int AMODE, int BMODE, bool FAST, bool KLIST = false>
 __global__ __launch_bounds__(256) void sgemm_kernel(asr_gemm_desc d, int vecA, int vecB, int ktiles_per_split) {
     constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
     __shared__ __attribute__((aligned(16))) float As[2][GK][BM + GPAD(AMODE)];
@@ -173,13 +188,18 @@ __global__ __launch_bounds__(256) void sgemm_kernel(asr_gemm_desc d, int vecA, i
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     float4 ra[BM * GK / 1024], rb[BN * GK / 1024];
-    TileLoader<BM, GK, AMODE, FAST> la;
-    TileLoader<BN, GK, BMODE, FAST> lb;
-    la.init(va, m0, d.M);
-    lb.init(vb, n0, d.N);
+    static_assert(!KLIST || (AMODE == 1 && BMODE == 1), "a k row list indexes the rows of both operands");
+    TileLoader<BM, GK, AMODE, FAST, KLIST> la;
+    TileLoader<BN, GK, BMODE, FAST, KLIST> lb;
+    const int32_t *kidx = d.k_idx;
+    const int klast = d.K - 1;
+    la.init(va, m0, d.M, AMODE == 0 ? d.m_idx : nullptr);
+    lb.init(vb, n0, d.N, nullptr);
     if (nk > 0) {
-        la.load(va, d.M, kbeg, kend, vecA, ra);
-        lb.load(vb, d.N, kbeg, kend, vecB, rb);
+        la.init_klist(kidx, kbeg, klast);
+        lb.init_klist(kidx, kbeg, klast);
+        la.load(va, d.M, kbeg, kend, vecA, ra, kidx, klast);
+        lb.load(vb, d.N, kbeg, kend, vecB, rb, kidx, klast);
         la.apply_mask(ra);
         lb.apply_mask(rb);
         store_tile<BM, GK, AMODE>(As[0], ra);
@@ -191,8 +211,8 @@ __global__ __launch_bounds__(256) void sgemm_kernel(asr_gemm_desc d, int vecA, i
     for (int kt = 0; kt < nk; ++kt) {
         const bool more = kt + 1 < nk;
         if (more) {
-            la.load(va, d.M, kbeg + (kt + 1) * GK, kend, vecA, ra);
-            lb.load(vb, d.N, kbeg + (kt + 1) * GK, kend, vecB, rb);
+            la.load(va, d.M, kbeg + (kt + 1) * GK, kend, vecA, ra, kidx, klast);
+            lb.load(vb, d.N, kbeg + (kt + 1) * GK, kend, vecB, rb, kidx, klast);
         }
         const int kh = lane >> 5, l31 = lane & 31;
         // all LDS operand reads of the k-tile first, then the MFMAs: the reads stream in under the
@@ -233,7 +253,7 @@ __global__ __launch_bounds__(256) void sgemm_kernel(asr_gemm_desc d, int vecA, i
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int row = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-            coff[r] = row < d.M ? view_rowoff(vc, row) : -1;
+            coff[r] = row < d.M ? view_rowoff(vc, d.m_idx ? d.m_idx[row] : row) : -1;
         }
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
@@ -277,7 +297,11 @@ extern "C" int asr_sgemm(const asr_gemm_desc *din, void *stream) {
     if (d.c_d <= 0) d.c_d = 0x7fffffff;
     ASR_CHECK_ARG(!(d.splitk > 1 && d.act != 0), "sgemm: activation needs splitk == 1");
     ASR_CHECK_ARG(d.act == 0 || d.act == 1, "sgemm: bad act %d", d.act);
+    ASR_CHECK_ARG(!d.m_idx || (d.a_mode == 0 && d.nbatch == 1), "sgemm: m_idx needs a_mode 0 and nbatch 1");
+    ASR_CHECK_ARG(!d.k_idx || (d.a_mode == 1 && d.b_mode == 1 && d.nbatch == 1),
+                  "sgemm: k_idx needs a_mode 1, b_mode 1 and nbatch 1");
     if (d.M == 0 || d.N == 0) return ASR_OK;
+    if (d.K == 0) d.k_idx = nullptr;
 
     auto strides_ok = [&](int64_t s0, int64_t s1, int64_t sb) {
         return (s0 % 4 == 0) && (s1 % 4 == 0 || s1 == 0) && (sb % 4 == 0);
@@ -307,12 +331,17 @@ extern "C" int asr_sgemm(const asr_gemm_desc *din, void *stream) {
     const int sel = d.a_mode * 2 + d.b_mode;
 #define LAUNCH(BM_, BN_, GK_, AM, BM2, F)                                                              \
     hipLaunchKernelGGL((sgemm_kernel<BM_, BN_, GK_, AM, BM2, F>), grid, dim3(256), 0, st, d, vecA, vecB, per)
+#define LAUNCH_KLIST(BM_, BN_, GK_, F)                                                                 \
+    hipLaunchKernelGGL((sgemm_kernel<BM_, BN_, GK_, 1, 1, F, true>), grid, dim3(256), 0, st, d, vecA, vecB, per)
 #define LAUNCH_MODES(BM_, BN_, GK_, F)                    \
     switch (sel) {                                        \
         case 0: LAUNCH(BM_, BN_, GK_, 0, 0, F); break;    \
         case 1: LAUNCH(BM_, BN_, GK_, 0, 1, F); break;    \
         case 2: LAUNCH(BM_, BN_, GK_, 1, 0, F); break;    \
-        default: LAUNCH(BM_, BN_, GK_, 1, 1, F); break;   \
+        default:                                          \
+            if (d.k_idx) LAUNCH_KLIST(BM_, BN_, GK_, F);  \
+            else LAUNCH(BM_, BN_, GK_, 1, 1, F);          \
+            break;                                        \
     }
     static int tile_cfg = -1;
     if (tile_cfg < 0) {
@@ -343,6 +372,7 @@ extern "C" int asr_sgemm(const asr_gemm_desc *din, void *stream) {
         if (fast) { LAUNCH_MODES(64, 64, 16, true) } else { LAUNCH_MODES(64, 64, 16, false) }
     }
 #undef LAUNCH_MODES
+#undef LAUNCH_KLIST
 #undef LAUNCH
     ASR_CHECK_LAUNCH("sgemm_kernel");
     return ASR_OK;

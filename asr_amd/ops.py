@@ -30,11 +30,13 @@ def _req(t, dtype=torch.float32):
 
 def sgemm(A, B, Cm, M, N, K, *, a_mode=0, b_mode=0, a_stride=None, b_stride=None, c_stride=None,
           a_two=None, b_two=None, c_two=None, bias1=None, bias2=None, alpha=1.0, accumulate=False,
-          act=0, splitk=1, nbatch=1, batch_a=0, batch_b=0, batch_c=0, a_off=0, b_off=0, c_off=0):
+          act=0, splitk=1, nbatch=1, batch_a=0, batch_b=0, batch_c=0, a_off=0, b_off=0, c_off=0,
+          m_idx=None, k_idx=None):
     """C[m,n] (+)= alpha * sum_k A(m,k) B(n,k) (+ biases); see include/asr_amd.h.
 
     *_stride: single row stride (elements); *_two = (d, s0, s1): two-level row
     offset (i // d) * s1 + (i % d) * s0.  *_off: element offsets into the tensors.
+    m_idx / k_idx: int32 device row lists (M resp. K then count list entries).
     """
     lib = _lib.load()
     d = GemmDesc()
@@ -60,6 +62,13 @@ def sgemm(A, B, Cm, M, N, K, *, a_mode=0, b_mode=0, a_stride=None, b_stride=None
     d.splitk = splitk
     d.nbatch = nbatch
     d.batch_a, d.batch_b, d.batch_c = batch_a, batch_b, batch_c
+    for name, idx, n in (("m_idx", m_idx, M), ("k_idx", k_idx, K)):
+        if idx is None:
+            setattr(d, name, 0)
+            continue
+        if not idx.is_cuda or idx.dtype != torch.int32 or not idx.is_contiguous() or idx.numel() < n:
+            raise RuntimeError(f"asr_amd.sgemm: {name} must be a contiguous int32 device tensor of >= {n} entries")
+        setattr(d, name, idx.data_ptr())
     check(lib.asr_sgemm(C.byref(d), _stream()))
 
 

@@ -71,6 +71,15 @@ int asr_ls_ce_fwd_bwd(const float *logits, const int64_t *targets, const int64_t
  * nbatch > 1 runs independent problems at pointer strides batch_{a,b,c}.
  * splitk > 1 splits K over blocks and accumulates with float atomics: C must
  * then hold the initial value (accumulate is implied).
+ * Row lists (device int32, may be NULL) let a ragged batch skip its padded frames the way
+ * pack_padded_sequence does for nn.LSTM (Models/encoder.py:32): the products then run over the
+ * listed rows only.
+ *   m_idx (a_mode 0 only): M counts list entries; entry m names the row of A and of C:
+ *          A(m,k) at A[rowoff_a(m_idx[m]) + k], C(m,n) at C[rowoff_c(m_idx[m]) + n].
+ *          Rows of C that are not listed are left untouched.
+ *   k_idx (a_mode 1 and b_mode 1 only): K counts list entries; entry k names the row of both
+ *          operands: A(m,k) at A[rowoff_a(k_idx[k]) + m], B(n,k) at B[rowoff_b(k_idx[k]) + n].
+ * Every entry must be a row inside the operand; the library cannot check device data.
  */
 typedef struct {
     const float *A, *B;
@@ -87,6 +96,7 @@ typedef struct {
     int splitk;
     int nbatch;
     int64_t batch_a, batch_b, batch_c;
+    const int32_t *m_idx, *k_idx;   /* row lists, see above (nbatch must be 1 with either) */
 } asr_gemm_desc;
 
 int asr_sgemm(const asr_gemm_desc *d, void *stream);

@@ -79,6 +79,43 @@ def test_sgemm_two_level_and_batched():
     assert rel_err(dh.cpu(), want) < 2e-6
 
 
+@pytest.mark.parametrize("R,N,K,keep", [(9, 5, 3, 0.6), (300, 130, 40, 0.8), (2000, 256, 64, 0.75),
+                                        (17000, 1280, 240, 0.8), (40, 12, 8, 1.0)])
+def test_sgemm_row_lists(R, N, K, keep):
+    """m_idx / k_idx: the products over a list of rows equal the dense products over those rows,
+    unlisted rows of C stay untouched (a ragged batch skipping its padded frames)."""
+    from asr_amd import ops
+    dev = _dev()
+    g = torch.Generator().manual_seed(R + N + K)
+    rows = torch.nonzero(torch.rand(R, generator=g) < keep).flatten().to(torch.int32)
+    if keep == 1.0:
+        rows = torch.arange(R, dtype=torch.int32)
+    rows = rows[torch.randperm(rows.numel(), generator=g)] if R < 100 else rows     # any order is allowed
+    n = rows.numel()
+    X = torch.randn(R, K, generator=g)
+    W = torch.randn(N, K, generator=g)
+    idx = rows.to(dev)
+    Xd, Wd = X.to(dev), W.to(dev)
+    for b_mode, Wop in ((0, Wd), (1, Wd.t().contiguous())):
+        out = torch.full((R, N), 7.0, device=dev)
+        ops.sgemm(Xd, Wop, out, n, N, K, b_mode=b_mode, a_stride=K, b_stride=Wop.shape[1], c_stride=N, m_idx=idx)
+        want = torch.full((R, N), 7.0, dtype=torch.float64)
+        want[rows.long()] = X.double()[rows.long()] @ W.double().t()
+        assert rel_err(out.cpu(), want) < 2e-6
+    # weight-gradient form: dW (N x K) = sum over listed rows of dY[r]^T X[r]
+    dY = torch.randn(R, N, generator=g)
+    dYd = dY.to(dev)
+    want = dY.double()[rows.long()].t() @ X.double()[rows.long()]
+    for sk in (1, 3):
+        gW = torch.zeros(N, K, device=dev)
+        ops.sgemm(dYd, Xd, gW, N, K, n, a_mode=1, a_stride=N, b_mode=1, b_stride=K, c_stride=K, splitk=sk, k_idx=idx)
+        assert rel_err(gW.cpu(), want) < 1e-5      # fp32 sums over up to 13 600 rows
+    with pytest.raises(RuntimeError):
+        ops.sgemm(dYd, Xd, gW, N, K, n, a_mode=1, a_stride=N, b_mode=1, b_stride=K, c_stride=K, m_idx=idx)
+    with pytest.raises(RuntimeError):
+        ops.sgemm(Xd, Wd, out, n, N, K, a_stride=K, b_stride=K, c_stride=N, k_idx=idx)
+
+
 def test_helpers():
     from asr_amd import ops
     dev = _dev()
