@@ -76,7 +76,11 @@ SYMBOLS = {
     "asr_scatter_rows": (C.c_int, [c_f, c_f, C.c_int, C.c_int, c_i64, c_f, C.c_int, c_f]),
     "asr_mul_dtanh": (C.c_int, [c_f, c_f, c_f, c_i64, c_f]),
     "asr_scale": (C.c_int, [c_f, c_i64, C.c_float, c_f]),
+    "asr_argmax_rows": (C.c_int, [c_f, c_i64, C.c_int, c_i64, c_f, c_f]),
     "asr_sqnorm_ws_floats": (c_i64, []),
+    "asr_ctc_ws_floats": (c_i64, [C.c_int, C.c_int, C.c_int]),
+    "asr_ctc_loss_fwd_bwd": (C.c_int, [c_f, c_f, c_f, c_f, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                       c_f, c_f, c_f, c_f, c_f]),
     "asr_grad_sqnorm": (C.c_int, [C.POINTER(TensorList), c_f, C.c_int, c_f, c_f]),
     "asr_clip_adam_step": (C.c_int, [C.POINTER(TensorList)] * 4 + [c_f] + [C.c_double] * 6 + [c_i64, c_f]),
     "asr_blstm_ws_floats": (c_i64, [C.c_int, C.c_int]),

@@ -273,3 +273,41 @@ extern "C" int asr_scale(float *x, int64_t n, float s, void *stream) {
     ASR_CHECK_LAUNCH("scale_kernel");
     return ASR_OK;
 }
+
+// ---------------------------------------------------------------------------
+// out[r] = index of the first maximum of row r (torch.argmax's tie rule for the frame-wise
+// labels of CTCModel.decode, Models/CTCModel.py:33): one wave per row.
+__global__ __launch_bounds__(256) void argmax_rows_kernel(const float *__restrict__ x, int64_t rows, int cols,
+                                                          int64_t ld, int64_t *__restrict__ out) {
+    const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (r >= rows) return;
+    const float *xr = x + r * ld;
+    float best = -INFINITY;
+    int bi = 0x7fffffff;
+    for (int c = lane; c < cols; c += 64) {
+        const float v = xr[c];
+        if (v > best || (v == best && c < bi) || (v != v && !(best != best))) { best = v; bi = c; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ob = __shfl_xor(best, o, 64);
+        const int oi = __shfl_xor(bi, o, 64);
+        const bool onan = ob != ob, bnan = best != best;
+        // torch treats NaN as the maximum; among equals the lower index wins
+        const bool take = bnan ? (onan && oi < bi) : (onan || ob > best || (ob == best && oi < bi));
+        if (take) { best = ob; bi = oi; }
+    }
+    if (lane == 0) out[r] = bi == 0x7fffffff ? 0 : bi;
+}
+
+extern "C" int asr_argmax_rows(const float *x, int64_t rows, int cols, int64_t ld, int64_t *out, void *stream) {
+    ASR_CHECK_ARG(x && out, "argmax_rows: null pointer");
+    ASR_CHECK_ARG(rows >= 0 && cols > 0 && ld >= cols, "argmax_rows: bad shape");
+    if (rows == 0) return ASR_OK;
+    ASR_CHECK_ARG(cdiv(rows, 4) <= 0x7fffffff, "argmax_rows: too many rows");
+    hipLaunchKernelGGL(argmax_rows_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, x, rows, cols,
+                       ld, out);
+    ASR_CHECK_LAUNCH("argmax_rows_kernel");
+    return ASR_OK;
+}

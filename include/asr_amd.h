@@ -52,6 +52,25 @@ int asr_ls_ce_fwd_bwd(const float *logits, const int64_t *targets, const int64_t
                       int B, int L, int V, float eps, int T_norm, int B_norm,
                       float *row_loss, float *loss, float *dlogits, void *stream);
 
+/* ------------------------------------------------------------------- ctc --
+ * The CTC head's loss: replaces train.py:56-57,
+ *   predict_ts = F.log_softmax(predict_ts, dim=2).transpose(0, 1)
+ *   loss = F.ctc_loss(predict_ts, text, mel_lengths, text_lengths, blank=0)
+ * (reduction 'mean': mean over the batch of nll_b / max(target_length_b, 1); zero_infinity
+ * False) and its backward through the log_softmax, in one call.
+ *   logits (B,T,V) f32, the output of CTCModel.forward (Models/CTCModel.py:19-23)
+ *   targets (B,L) i64 (may be NULL when L == 0); input_lengths, target_lengths (B) i32, all on the device
+ *   ws      asr_ctc_ws_floats(B,T,L) floats of scratch
+ *   nll     (B) f32 out: per-utterance negative log likelihood (reduction 'none')
+ *   loss    (1) f32 out
+ *   dlogits (B,T,V) f32 out: d loss / d logits, 0 for frames t >= input_lengths[b]
+ * L <= 511.  An utterance whose labels do not fit its frames has nll = +inf, as in torch.
+ */
+int64_t asr_ctc_ws_floats(int B, int T, int L);
+int asr_ctc_loss_fwd_bwd(const float *logits, const int64_t *targets, const int32_t *input_lengths,
+                         const int32_t *target_lengths, int B, int T, int V, int L, int blank,
+                         float *ws, float *nll, float *loss, float *dlogits, void *stream);
+
 /* ------------------------------------------------------------------ gemm --
  * fp32 MFMA GEMM used for every hoisted matrix product of the path:
  * the per-layer LSTM input projections and their gradients (the GEMMs inside
@@ -118,6 +137,9 @@ int asr_scatter_rows(const float *src, const int64_t *idx, int n_rows, int width
 int asr_mul_dtanh(const float *dU, const float *U, float *out, int64_t n, void *stream);
 /* x *= s (1/world_size after the gradient all-reduce: DDP averages, train.py:141) */
 int asr_scale(float *x, int64_t n, float s, void *stream);
+/* out[r] = argmax_c x[r*ld + c], first maximum (the frame-wise labels of CTCModel.decode,
+ * Models/CTCModel.py:33: decoder_output[b].argmax(dim=1)) */
+int asr_argmax_rows(const float *x, int64_t rows, int cols, int64_t ld, int64_t *out, void *stream);
 
 /* ------------------------------------------------- optimizer step (next) --
  * The caller-side tail of the step, train.py:60-63 with the optimizer built at train.py:146:

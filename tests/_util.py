@@ -12,8 +12,13 @@ CASES = sorted(os.path.splitext(os.path.basename(p))[0]
                for p in glob.glob(os.path.join(GOLDEN_DIR, "*.npz")))
 
 
+CTC_CASES = sorted(os.path.splitext(os.path.basename(p))[0]
+                   for p in glob.glob(os.path.join(GOLDEN_DIR, "ctc", "*.npz")))
+
+
 def load_case(name):
-    z = np.load(os.path.join(GOLDEN_DIR, name + ".npz"), allow_pickle=False)
+    sub = "ctc" if name.startswith("ctc_") else ""
+    z = np.load(os.path.join(GOLDEN_DIR, sub, name + ".npz"), allow_pickle=False)
     hp = types.SimpleNamespace(**dict(ast.literal_eval(str(z["meta_hp"]))))
     return z, hp
 
