@@ -95,6 +95,9 @@ PIPE_BWD = os.environ.get("ASR_PIPE_BWD", "1") != "0"
 
 
 # Row lists: when at least this share of the (T x B) frames is padding, the layer GEMMs skip it.
+# One launch for both directions of a layer's input projection and of its dX (two-level views
+# over the separate forward / reverse parameter tensors); ASR_MERGE_DIRECTIONS=0 restores two.
+MERGE_DIRECTIONS = os.environ.get("ASR_MERGE_DIRECTIONS", "1") != "0"
 ROW_LIST_MIN_PADDING = float(os.environ.get("ASR_ROW_LIST_MIN_PADDING", "0.04"))
 
 
@@ -157,10 +160,21 @@ class _BLSTMLayerFunction(torch.autograd.Function):
     nxt: _Next to fill for the layer above (the output is then already dropped out) or None."""
 
     @staticmethod
-    def forward(ctx, inp, lengths_dev, rl, first, last, H, pre, nxt, w_ih_f, w_hh_f, b_ih_f, b_hh_f, w_ih_r,
-                w_hh_r, b_ih_r, b_hh_r):
+    def forward(ctx, inp, lengths_dev, rl, first, last, H, pre, nxt, in_drop, w_ih_f, w_hh_f, b_ih_f, b_hh_f,
+                w_ih_r, w_hh_r, b_ih_r, b_hh_r):
+        """in_drop = (p, seed) or None: inverted dropout applied to the input inside this node (the
+        dropout between two nn.LSTM layers, Models/encoder.py:26), so that its backward fuses into
+        the epilogue of the dX product."""
         lib = _lib.load()
         inp = inp.contiguous()
+        in_keep, in_scale = None, 1.0
+        if in_drop is not None and in_drop[0] > 0.0:
+            raw = inp
+            inp = torch.empty_like(raw)
+            in_keep = torch.empty(raw.numel(), device=raw.device, dtype=torch.uint8)
+            in_scale = 1.0 / (1.0 - in_drop[0])
+            check(lib.asr_dropout_fwd(raw.data_ptr(), inp.data_ptr(), in_keep.data_ptr(), raw.numel(),
+                                      C.c_float(in_drop[0]), C.c_uint64(in_drop[1]), _stream()))
         if first:
             B, T, D = inp.shape
             in_two = (B, T * D, D)         # row (t*B + b) of the GEMM <-> inp[b, t]
@@ -178,9 +192,16 @@ class _BLSTMLayerFunction(torch.autograd.Function):
             # overwrites them with the zeros its backward expects
             G = torch.empty(T, B, 2, 4 * H, **f32)
             rows, nrows = (rl.rows, rl.n) if rl is not None else (None, T * B)
-            for d, (w_ih, b_ih, b_hh) in enumerate(((w_ih_f, b_ih_f, b_hh_f), (w_ih_r, b_ih_r, b_hh_r))):
-                ops.sgemm(inp, w_ih, G, nrows, 4 * H, D, a_two=in_two, b_stride=D, c_stride=8 * H,
-                          c_off=d * 4 * H, bias1=b_ih, bias2=b_hh, m_idx=rows)
+            dw, db1, db2 = ops.elem_delta(w_ih_f, w_ih_r), ops.elem_delta(b_ih_f, b_ih_r), ops.elem_delta(b_hh_f, b_hh_r)
+            if MERGE_DIRECTIONS and None not in (dw, db1, db2):
+                # both directions in one launch: the reverse direction's weights and biases are
+                # reached through the two-level row / bias maps, nothing is concatenated
+                ops.sgemm(inp, w_ih_f, G, nrows, 8 * H, D, a_two=in_two, b_two=(4 * H, D, dw), c_stride=8 * H,
+                          bias1=b_ih_f, bias2=b_hh_f, bias_two=(4 * H, db1, db2), m_idx=rows)
+            else:
+                for d, (w_ih, b_ih, b_hh) in enumerate(((w_ih_f, b_ih_f, b_hh_f), (w_ih_r, b_ih_r, b_hh_r))):
+                    ops.sgemm(inp, w_ih, G, nrows, 4 * H, D, a_two=in_two, b_stride=D, c_stride=8 * H,
+                              c_off=d * 4 * H, bias1=b_ih, bias2=b_hh, m_idx=rows)
         W_hh = torch.cat([w_hh_f, w_hh_r], 0)      # [2][4H][H]
         if last:
             Hout = torch.empty(B, T, 2 * H, **f32)
@@ -236,6 +257,8 @@ class _BLSTMLayerFunction(torch.autograd.Function):
         ctx.p = nxt.p if mask is not None else 0.0
         ctx.dims = (B, T, D, H, first, in_two, ho_t, ho_b)
         ctx.rl = rl
+        ctx.in_keep, ctx.in_scale = in_keep, in_scale
+        ctx.in_p = in_drop[0] if in_keep is not None else 0.0
         return out
 
     @staticmethod
@@ -273,9 +296,16 @@ class _BLSTMLayerFunction(torch.autograd.Function):
                 # reads them (its recurrence masks by length); the caller of the first layer might
                 rows, nrows = (rl.rows, rl.n) if rl is not None else (None, T * B)
                 dIn = torch.zeros_like(inp) if (first and rl is not None) else torch.empty_like(inp)
-                for d, w_ih in enumerate((w_ih_f, w_ih_r)):
-                    ops.sgemm(dG, w_ih, dIn, nrows, D, 4 * H, a_stride=8 * H, a_off=d * 4 * H, b_mode=1,
-                              b_stride=D, c_two=in_two, accumulate=(d == 1), m_idx=rows)
+                keep, ks = ctx.in_keep, ctx.in_scale      # dropout of the input: its backward rides the epilogue
+                dw = ops.elem_delta(w_ih_f, w_ih_r)
+                if MERGE_DIRECTIONS and dw is not None:
+                    ops.sgemm(dG, w_ih_f, dIn, nrows, D, 8 * H, a_stride=8 * H, b_mode=1, b_two=(4 * H, D, dw),
+                              c_two=in_two, m_idx=rows, keep=keep, keep_scale=ks)
+                else:
+                    for d, w_ih in enumerate((w_ih_f, w_ih_r)):
+                        ops.sgemm(dG, w_ih, dIn, nrows, D, 4 * H, a_stride=8 * H, a_off=d * 4 * H, b_mode=1,
+                                  b_stride=D, c_two=in_two, accumulate=(d == 1), m_idx=rows,
+                                  keep=keep if d == 1 else None, keep_scale=ks)
         else:
             # time-major input (T,B,D): the rows of a frame range are contiguous in dG and dX
             dIn = torch.empty_like(inp)
@@ -298,6 +328,9 @@ class _BLSTMLayerFunction(torch.autograd.Function):
                                   a_off=t0 * B * 8 * H + d * 4 * H, b_mode=1, b_stride=D, c_stride=D,
                                   c_off=t0 * B * D, accumulate=True)
             main.wait_stream(pipe)
+            if ctx.in_keep is not None:
+                check(lib.asr_dropout_bwd(dIn.data_ptr(), ctx.in_keep.data_ptr(), dIn.data_ptr(), dIn.numel(),
+                                          C.c_float(ctx.in_p), st))
         # weight / bias gradients: nothing downstream reads them -> side stream, overlapping the
         # next layer's (latency-bound) recurrence kernel
         hout_two = (B, ho_b, ho_t)                 # row (t*B + b) <-> Hout element offset
@@ -334,7 +367,7 @@ class _BLSTMLayerFunction(torch.autograd.Function):
                 ops.sgemm(dG, inp, gWi, 4 * H, D, K, a_mode=1, a_stride=8 * H, a_off=d * 4 * H, b_mode=1,
                           b_two=in_two, c_stride=D, splitk=sk, k_idx=kl)
                 grads[d] = (gWi, gW, db[d * 4 * H:(d + 1) * 4 * H], db[d * 4 * H:(d + 1) * 4 * H].clone())
-        return (dIn, None, None, None, None, None, None, None) + grads[0] + grads[1]
+        return (dIn, None, None, None, None, None, None, None, None) + grads[0] + grads[1]
 
 
 class _DropoutFunction(torch.autograd.Function):
@@ -385,15 +418,15 @@ class Encoder(nn.Module):
         T = h.shape[1]
         pipelined = streams.ENABLED and PIPE_FWD and PIPE_CHUNKS > 1 and T >= PIPE_MIN_T
         pre = None
+        in_drop = None        # dropout between layers: applied by the consuming layer (fused backward)
         for layer in range(self.num_layers):
             last = layer == self.num_layers - 1
             nxt = None
             if pipelined and not last:
                 n = flat[8 * (layer + 1): 8 * (layer + 1) + 8]     # (w_ih, w_hh, b_ih, b_hh) x (fwd, rev)
                 nxt = _Next(n[0], n[2], n[3], n[4], n[6], n[7], p, seed + 7919 * layer)
-            h = _BLSTMLayerFunction.apply(h, lengths_dev, rl, layer == 0, last, self.hidden, pre, nxt,
+            h = _BLSTMLayerFunction.apply(h, lengths_dev, rl, layer == 0, last, self.hidden, pre, nxt, in_drop,
                                           *flat[8 * layer: 8 * layer + 8])
-            if nxt is None and p > 0.0 and not last:
-                h = _DropoutFunction.apply(h, p, seed + 7919 * layer)
+            in_drop = (p, seed + 7919 * layer) if (nxt is None and p > 0.0 and not last) else None
             pre = nxt
         return h

@@ -30,6 +30,8 @@ class GemmDesc(C.Structure):
         ("nbatch", C.c_int),
         ("batch_a", c_i64), ("batch_b", c_i64), ("batch_c", c_i64),
         ("m_idx", c_f), ("k_idx", c_f),
+        ("bias_d", C.c_int), ("bias1_s1", c_i64), ("bias2_s1", c_i64),
+        ("c_keep", c_f), ("c_keep_scale", C.c_float),
     ]
 
 

@@ -261,8 +261,9 @@ __global__ __launch_bounds__(256) void sgemm_kernel(asr_gemm_desc d, int vecA, i
             if (col >= d.N) continue;
             float bias = 0.f;
             if (first) {
-                if (d.bias1) bias += d.bias1[col];
-                if (d.bias2) bias += d.bias2[col];
+                const int bh = d.bias_d > 0 ? col / d.bias_d : 0, bl = col - bh * (d.bias_d > 0 ? d.bias_d : 0);
+                if (d.bias1) bias += d.bias1[bh * d.bias1_s1 + bl];
+                if (d.bias2) bias += d.bias2[bh * d.bias2_s1 + bl];
             }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -274,6 +275,7 @@ __global__ __launch_bounds__(256) void sgemm_kernel(asr_gemm_desc d, int vecA, i
                 } else {
                     if (d.accumulate) v += *dst;
                     if (d.act == 1) v = tanh_f(v);
+                    if (d.c_keep) v = d.c_keep[(dst - d.C)] ? v * d.c_keep_scale : 0.f;
                     *dst = v;
                 }
             }
@@ -300,6 +302,8 @@ extern "C" int asr_sgemm(const asr_gemm_desc *din, void *stream) {
     ASR_CHECK_ARG(!d.m_idx || (d.a_mode == 0 && d.nbatch == 1), "sgemm: m_idx needs a_mode 0 and nbatch 1");
     ASR_CHECK_ARG(!d.k_idx || (d.a_mode == 1 && d.b_mode == 1 && d.nbatch == 1),
                   "sgemm: k_idx needs a_mode 1, b_mode 1 and nbatch 1");
+    ASR_CHECK_ARG(!d.c_keep || (d.splitk == 1 && d.nbatch == 1), "sgemm: c_keep needs splitk 1 and nbatch 1");
+    ASR_CHECK_ARG(d.bias_d >= 0, "sgemm: negative bias_d");
     if (d.M == 0 || d.N == 0) return ASR_OK;
     if (d.K == 0) d.k_idx = nullptr;
 

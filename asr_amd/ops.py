@@ -31,12 +31,14 @@ def _req(t, dtype=torch.float32):
 def sgemm(A, B, Cm, M, N, K, *, a_mode=0, b_mode=0, a_stride=None, b_stride=None, c_stride=None,
           a_two=None, b_two=None, c_two=None, bias1=None, bias2=None, alpha=1.0, accumulate=False,
           act=0, splitk=1, nbatch=1, batch_a=0, batch_b=0, batch_c=0, a_off=0, b_off=0, c_off=0,
-          m_idx=None, k_idx=None):
+          m_idx=None, k_idx=None, bias_two=None, keep=None, keep_scale=1.0):
     """C[m,n] (+)= alpha * sum_k A(m,k) B(n,k) (+ biases); see include/asr_amd.h.
 
     *_stride: single row stride (elements); *_two = (d, s0, s1): two-level row
     offset (i // d) * s1 + (i % d) * s0.  *_off: element offsets into the tensors.
     m_idx / k_idx: int32 device row lists (M resp. K then count list entries).
+    bias_two = (d, s1_bias1, s1_bias2): two-level bias index.  keep / keep_scale: uint8 mask laid
+    out like C, applied to the stored value (fused dropout backward).
     """
     lib = _lib.load()
     d = GemmDesc()
@@ -62,6 +64,9 @@ def sgemm(A, B, Cm, M, N, K, *, a_mode=0, b_mode=0, a_stride=None, b_stride=None
     d.splitk = splitk
     d.nbatch = nbatch
     d.batch_a, d.batch_b, d.batch_c = batch_a, batch_b, batch_c
+    d.bias_d, d.bias1_s1, d.bias2_s1 = (0, 0, 0) if bias_two is None else bias_two
+    d.c_keep = 0 if keep is None else keep.data_ptr()
+    d.c_keep_scale = keep_scale
     for name, idx, n in (("m_idx", m_idx, M), ("k_idx", k_idx, K)):
         if idx is None:
             setattr(d, name, 0)
@@ -70,6 +75,13 @@ def sgemm(A, B, Cm, M, N, K, *, a_mode=0, b_mode=0, a_stride=None, b_stride=None
             raise RuntimeError(f"asr_amd.sgemm: {name} must be a contiguous int32 device tensor of >= {n} entries")
         setattr(d, name, idx.data_ptr())
     check(lib.asr_sgemm(C.byref(d), _stream()))
+
+
+def elem_delta(a, b):
+    """Element distance from tensor a to tensor b (both fp32) if a two-level GEMM view can
+    address them as one operand (16-byte aligned distance), else None."""
+    diff = b.data_ptr() - a.data_ptr()
+    return diff // 4 if diff % 16 == 0 else None
 
 
 def pick_splitk(M, N, K, nbatch=1):

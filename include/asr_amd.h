@@ -116,6 +116,16 @@ typedef struct {
     int nbatch;
     int64_t batch_a, batch_b, batch_c;
     const int32_t *m_idx, *k_idx;   /* row lists, see above (nbatch must be 1 with either) */
+    /* bias_d > 0: the bias vectors are two-level like the rows, column n reads
+     * bias1[(n / bias_d) * bias1_s1 + n % bias_d] (resp. bias2, bias2_s1): the forward and the
+     * reverse direction's biases of an nn.LSTM layer are separate tensors, one launch serves both */
+    int bias_d;
+    int64_t bias1_s1, bias2_s1;
+    /* c_keep != NULL (splitk 1): the stored value becomes c_keep[off] ? v * c_keep_scale : 0 with
+     * off the element offset of C(m,n): the backward of the inverted dropout that produced the
+     * GEMM's consumer (nn.LSTM(dropout=p), Models/encoder.py:26), fused into the dX epilogue */
+    const uint8_t *c_keep;
+    float c_keep_scale;
 } asr_gemm_desc;
 
 int asr_sgemm(const asr_gemm_desc *d, void *stream);

@@ -116,6 +116,42 @@ def test_sgemm_row_lists(R, N, K, keep):
         ops.sgemm(Xd, Wd, out, n, N, K, a_stride=K, b_stride=K, c_stride=N, k_idx=idx)
 
 
+def test_sgemm_two_tensor_operand_and_fused_keep():
+    """One launch over two separately allocated weight / bias tensors (two-level views), and the
+    dropout-backward mask applied in the epilogue."""
+    from asr_amd import ops
+    dev = _dev()
+    g = torch.Generator().manual_seed(77)
+    M, K, Nh = 300, 48, 64
+    X = torch.randn(M, K, generator=g)
+    Wf, Wr = torch.randn(Nh, K, generator=g), torch.randn(Nh, K, generator=g)
+    bf1, br1 = torch.randn(Nh, generator=g), torch.randn(Nh, generator=g)
+    bf2, br2 = torch.randn(Nh, generator=g), torch.randn(Nh, generator=g)
+    junk = torch.empty(12345, device=dev)                       # keeps the two allocations apart
+    Wfd, Wrd, b1f, b1r, b2f, b2r = (t.to(dev) for t in (Wf, Wr, bf1, br1, bf2, br2))
+    dw, d1, d2 = ops.elem_delta(Wfd, Wrd), ops.elem_delta(b1f, b1r), ops.elem_delta(b2f, b2r)
+    assert None not in (dw, d1, d2)
+    out = torch.empty(M, 2 * Nh, device=dev)
+    ops.sgemm(X.to(dev), Wfd, out, M, 2 * Nh, K, a_stride=K, b_two=(Nh, K, dw), c_stride=2 * Nh,
+              bias1=b1f, bias2=b2f, bias_two=(Nh, d1, d2))
+    want = torch.cat([X.double() @ Wf.double().t() + bf1.double() + bf2.double(),
+                      X.double() @ Wr.double().t() + br1.double() + br2.double()], 1)
+    assert rel_err(out.cpu(), want) < 2e-6
+    # dX form: reduction over the rows of both weight tensors, mask in the epilogue
+    dG = torch.randn(M, 2 * Nh, generator=g)
+    keep = (torch.rand(M, K, generator=g) < 0.8).to(torch.uint8)
+    dX = torch.empty(M, K, device=dev)
+    ops.sgemm(dG.to(dev), Wfd, dX, M, K, 2 * Nh, a_stride=2 * Nh, b_mode=1, b_two=(Nh, K, dw), c_stride=K,
+              keep=keep.to(dev), keep_scale=1.25)
+    want = (dG.double() @ torch.cat([Wf, Wr], 0).double()) * keep.double() * 1.25
+    assert rel_err(dX.cpu(), want) < 2e-6
+    assert torch.equal(dX.cpu() == 0, keep == 0) or float((dX.cpu() == 0).sum()) >= float((keep == 0).sum())
+    with pytest.raises(RuntimeError):
+        ops.sgemm(dG.to(dev), Wfd, dX, M, K, 2 * Nh, a_stride=2 * Nh, b_mode=1, b_two=(Nh, K, dw), c_stride=K,
+                  keep=keep.to(dev), splitk=2)
+    del junk
+
+
 def test_helpers():
     from asr_amd import ops
     dev = _dev()
