@@ -1452,6 +1452,11 @@ __global__ __launch_bounds__(256) void phase2_mfma_kernel(
         if (s + 1 < L) fetch(s + 1);                       // uniform
         const float4 dv = *reinterpret_cast<const float4 *>(&des[buf][16 * wave + 4 * q]);
         const float dev[4] = {dv.x, dv.y, dv.z, dv.w};
+        // every term of this step carries a factor de[f]: a wave whose 16 frames all have de == 0
+        // (label steps past the utterance's text, where no gradient arrives; frames past its
+        // length) adds exact zeros -- skip its math (wave-uniform), keep the barrier
+        const bool live = __any(dv.x != 0.f || dv.y != 0.f || dv.z != 0.f || dv.w != 0.f);
+        if (live) {
         float fa[3], ff[4];
 #pragma unroll
         for (int ks = 0; ks < 3; ++ks) fa[ks] = Fs[buf][16 * wave + col][4 * ks + q];
@@ -1474,6 +1479,7 @@ __global__ __launch_bounds__(256) void phase2_mfma_kernel(
 #pragma unroll
             for (int r = 0; r < 4; ++r)
                 acc_fe[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(ff[r], dp[r], acc_fe[n], 0, 0, 0);
+        }
         }
         if (s + 1 < L) stage(buf ^ 1);
         __syncthreads();
