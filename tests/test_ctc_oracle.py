@@ -63,3 +63,42 @@ def test_torch_ctc_equals_textbook_recursion(name):
     assert rel_err(nll, want) < 1e-10
     mean = (nll / tl.clamp_min(1)).mean()
     assert abs(float(mean) - float(z["f64.loss"])) < 1e-10 * abs(float(z["f64.loss"]))
+
+
+# ------------------------------------------------ host mirror (no GPU needed) --
+@pytest.mark.parametrize("name", CTC_CASES)
+def test_ctc_mirror_state_dict_is_the_references(name):
+    from asr_amd.Models.CTCModel import CTCModel
+    z, hp = load_case(name)
+    m = CTCModel(hp)
+    want = {k[len("param."):]: tuple(z[k].shape) for k in z.files if k.startswith("param.")}
+    assert {k: tuple(v.shape) for k, v in m.state_dict().items()} == want
+    m.load_state_dict(params_of(z))       # strict
+
+
+def test_ctc_mirror_seeded_init_equals_oracle_init():
+    from asr_amd.Models.CTCModel import CTCModel
+    from oracle import ref_model as R
+    hp = R.make_hp(num_hidden_nodes=16, num_encoder_layer=2, lmfb_dim=4, num_classes=11, decoder_type="CTC")
+    torch.manual_seed(3)
+    a = CTCModel(hp).state_dict()
+    torch.manual_seed(3)
+    b = RC.CTCModel(hp).state_dict()
+    assert list(a) == list(b)
+    for k in a:
+        assert torch.equal(a[k], b[k]), k
+
+
+def test_ctc_mirror_has_no_cpu_fallback():
+    from asr_amd.Loss.ctc import ctc_loss
+    from asr_amd.Models.CTCModel import CTCModel
+    from oracle import ref_model as R
+    hp = R.make_hp(num_hidden_nodes=8, num_encoder_layer=1, lmfb_dim=4, num_classes=5, frame_stacking=1)
+    m = CTCModel(hp)
+    with pytest.raises(RuntimeError):
+        m(torch.zeros(1, 3, 4), torch.tensor([3]))
+    with pytest.raises(RuntimeError):
+        ctc_loss(torch.zeros(1, 3, 5), torch.ones(1, 2, dtype=torch.long), torch.tensor([3]), torch.tensor([2]))
+    hp.encoder_type = "Wave"
+    with pytest.raises(NotImplementedError):
+        CTCModel(hp)
