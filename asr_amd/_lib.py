@@ -80,6 +80,9 @@ SYMBOLS = {
     "asr_scale": (C.c_int, [c_f, c_i64, C.c_float, c_f]),
     "asr_argmax_rows": (C.c_int, [c_f, c_i64, C.c_int, c_i64, c_f, c_f]),
     "asr_sqnorm_ws_floats": (c_i64, []),
+    "asr_featurize_ws_floats": (c_i64, [C.c_int, C.c_int, C.c_int, C.c_int]),
+    "asr_featurize": (C.c_int, [c_f, c_f, c_f, c_f, c_f, C.c_int, C.c_int, c_f, C.c_int, C.c_int,
+                                C.c_int, C.c_int, C.c_int, c_f, c_f, c_f]),
     "asr_ctc_ws_floats": (c_i64, [C.c_int, C.c_int, C.c_int]),
     "asr_ctc_loss_fwd_bwd": (C.c_int, [c_f, c_f, c_f, c_f, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                        c_f, c_f, c_f, c_f, c_f]),

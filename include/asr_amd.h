@@ -71,6 +71,22 @@ int asr_ctc_loss_fwd_bwd(const float *logits, const int64_t *targets, const int3
                          const int32_t *target_lengths, int B, int T, int V, int L, int blank,
                          float *ws, float *nll, float *loss, float *dlogits, void *stream);
 
+/* ------------------------------------------------------------- features --
+ * Device-side input pipeline: replaces, for a whole padded batch,
+ * datasets.py:110-112 (x = (x - mean) / sqrt(var) per channel), datasets.py:52-81,118
+ * (SpecAugment: nF frequency masks [f0,f1) filled with the mean of the utterance as masked so
+ * far -- or 0 with fill_zero -- then nT time masks [t0,t1) filled with 0), the zero padding of
+ * collate_fn (datasets.py:225-247) and frame_stacking (utils/utils.py:47-65).
+ *   raw (B,Tm,F) f32 padded batch; mel_lengths (B) i32; mean, var (F) f32 or both NULL
+ *   fmask (B,nF,2), tmask (B,nT,2) i32 device lists of [begin,end) (empty ranges allowed);
+ *   the positions are drawn on the host exactly as the reference draws them
+ *   ws  asr_featurize_ws_floats(B,Tm,F,nF) floats;  out (B, Tm/stack, F*stack) f32
+ */
+int64_t asr_featurize_ws_floats(int B, int Tm, int F, int nF);
+int asr_featurize(const float *raw, const int32_t *mel_lengths, const float *mean, const float *var,
+                  const int32_t *fmask, int nF, int fill_zero, const int32_t *tmask, int nT, int stack,
+                  int B, int Tm, int F, float *ws, float *out, void *stream);
+
 /* ------------------------------------------------------------------ gemm --
  * fp32 MFMA GEMM used for every hoisted matrix product of the path:
  * the per-layer LSTM input projections and their gradients (the GEMMs inside
