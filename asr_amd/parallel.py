@@ -9,7 +9,16 @@ ends, overlapping the whole encoder backward), then encoder layers top-down --
 and each bucket is one flat fp32 buffer, so every all-reduce is a single large
 RCCL call (xGMI is point-to-point: few large messages beat many small ones).
 The 1/world_size of DDP's mean is applied with asr_scale when the bucket lands.
+
+Set ``TORCH_NCCL_HIGH_PRIORITY=1`` before ``init_process_group``: HIP multiplexes a process's
+streams onto a few hardware queues, and at normal priority RCCL's internal stream lands on the
+queue of the main stream, so a bucket's wait for its weight gradients (side stream) and the
+collective itself hold back the next layer's recurrence kernel queued behind them (measured in
+a group of one on MI355X: 37.8 ms per step without, 34.2 with; 33.4 with no reducer at all).
 """
+import os
+import warnings
+
 import torch
 import torch.distributed as dist
 
@@ -24,6 +33,11 @@ class BucketedGradReducer:
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         self.active = self.world > 1 or (force and dist.is_initialized())
+        if (self.active and dist.get_backend(process_group) == "nccl"
+                and os.environ.get("TORCH_NCCL_HIGH_PRIORITY", "0") not in ("1", "true", "True")):
+            warnings.warn("asr_amd.BucketedGradReducer: TORCH_NCCL_HIGH_PRIORITY=1 was not set before "
+                          "init_process_group; RCCL will share the main stream's hardware queue and the "
+                          "overlap with the backward is lost (see asr_amd/parallel.py)")
         # this reducer is stream-aware (see _launch): the weight gradients may be produced on the side stream
         streams.enable(True)
         enc, dec = model.encoder, model.decoder
