@@ -238,6 +238,79 @@ class Decoder(nn.Module):
                 return list(beams[0][0]), trace
         return [], trace
 
+    @torch.no_grad()
+    def decode_beam_v2(self, hbatch, lengths, beam_width, max_len, eos_id, score_func="log_softmax"):
+        """Models/decoder.py:132-267 (decode_v2, batch 1, no LM): the second beam search.
+
+        The ``beam_width`` live hypotheses are the batch rows of one attention step (:172-176; all
+        rows start from the zero state, :146-151).  Each row proposes its ``beam_width`` best tokens
+        (:195), scored ``old + (log-)probability + 1`` in float32 (:196: a bonus of 1 per token).
+        Step 0 keeps row 0's proposals as the first beam without looking at eos (:200-210).  Later
+        steps walk the best ``2 * beam_width`` of all proposals in score order (:212-214): one that
+        ends in eos is moved to the next free result slot (:222-230), any other fills the next beam
+        slot with its parent's state, context and attention (:231-244), until the beam is full or
+        ``beam_width`` results exist, which also ends the search (:246-255).  The answer is the
+        result slot with the highest score (:256-258) -- empty slots hold score 0 and length 0, so
+        [] comes back whenever every finished hypothesis scores below 0 (or none finished).
+
+        Raises RuntimeError as the reference does when 2 * decoder width != encoder output width
+        (the contexts are gathered into a buffer of that width, :219,241).
+        Returns (result, trace): trace[k] = (live survivors of step k as (tokens, score), results
+        finished so far as (tokens, score))."""
+        assert hbatch.size(0) == 1
+        W = int(beam_width)
+        if hbatch.size(2) != 2 * self.hd:
+            raise RuntimeError("decode_v2: encoder output width must be 2 * num_hidden_nodes_decoder")
+        T = hbatch.size(1)
+        e_mask = self._mask(hbatch, lengths)
+        s = hbatch.new_zeros(W, self.hd)
+        c = hbatch.new_zeros(W, self.hd)
+        alpha = hbatch.new_zeros(W, 1, T)
+        score = hbatch.new_zeros(W)
+        seqs = [[] for _ in range(W)]
+        done = []                                                   # (tokens, score), slot order
+        trace = []
+        for step in range(max_len):
+            g, alpha_n = self.att(s, hbatch, alpha, e_mask)
+            y = self.L_yy(torch.tanh(self.L_gy(g) + self.L_sy(s)))
+            y = F.log_softmax(y, dim=1) if score_func == "log_softmax" else F.softmax(y, dim=1)
+            best, idx = y.topk(W, dim=1)
+            cand = score.unsqueeze(1) + best + 1
+            if step == 0:
+                # all rows are identical here; row i keeps its own (zero) state
+                parents, toks, new_score = list(range(W)), idx[0].tolist(), cand[0].clone()
+            else:
+                k_scores, k_ix = cand.reshape(-1).topk(2 * W)
+                parents, toks, kept = [], [], []
+                for sc, ix in zip(k_scores.tolist(), k_ix.tolist()):
+                    h, j = ix // W, ix % W
+                    tok = int(idx[h, j])
+                    if tok == eos_id:
+                        done.append((seqs[h] + [tok], sc))
+                    else:
+                        parents.append(h)
+                        toks.append(tok)
+                        kept.append(sc)
+                    if len(parents) == W or len(done) >= W:
+                        break
+                if len(done) >= W:
+                    trace.append(([], list(done)))
+                    break
+                new_score = torch.tensor(kept, dtype=score.dtype)
+            sel = torch.tensor(parents)
+            rec = self.L_ys(torch.tensor(toks)) + self.L_ss(s[sel]) + self.L_gs(g[sel])
+            s, c = lstm_cell_tanh_form(rec, c[sel])
+            alpha = alpha_n[sel]
+            seqs = [seqs[h] + [t] for h, t in zip(parents, toks)]
+            score = new_score
+            trace.append(([(list(q), float(v)) for q, v in zip(seqs, score)], list(done)))
+        slots = [0.0] * W
+        for i, (_, sc) in enumerate(done[:W]):
+            slots[i] = sc
+        best_slot = max(range(W), key=lambda i: (slots[i], -i))    # argmax, first on ties
+        result = list(done[best_slot][0]) if best_slot < len(done) else []
+        return result, trace
+
 
 class AttModel(nn.Module):
     """Models/AttModel.py:10-39, BLSTM branch."""
@@ -259,6 +332,13 @@ class AttModel(nn.Module):
                                                 self.hp.eos_id, getattr(self.hp, "score_func", "log_softmax"))[0]
             return self.decoder.decode_greedy(
                 hbatch, lengths, self.hp.max_decoder_seq_len, self.hp.eos_id)[0]
+
+    def decode_v2(self, x, lengths, model_lm=None, src_pos=None):
+        """Models/AttModel.py:41-49."""
+        with torch.no_grad():
+            hbatch = self.encoder(x, lengths)
+            return self.decoder.decode_beam_v2(hbatch, lengths, self.hp.beam_width, self.hp.max_decoder_seq_len,
+                                               self.hp.eos_id, getattr(self.hp, "score_func", "log_softmax"))[0]
 
 
 # --------------------------------------------------------------------------

@@ -16,6 +16,17 @@ CTC_CASES = sorted(os.path.splitext(os.path.basename(p))[0]
                    for p in glob.glob(os.path.join(GOLDEN_DIR, "ctc", "*.npz")))
 
 
+V2_RUNS = (("v2beam3", 3, "log_softmax"), ("v2beam2sm", 2, "softmax"), ("v2beam4", 4, "log_softmax"),
+           ("v2beam6sm", 6, "softmax"))
+V2_CASES = sorted(os.path.splitext(os.path.basename(p))[0]
+                  for p in glob.glob(os.path.join(GOLDEN_DIR, "v2", "*.npz")))
+
+
+def load_v2(name):
+    """decode_v2 tables of the reference (oracle/make_golden_v2.py) for the case ``name``."""
+    return np.load(os.path.join(GOLDEN_DIR, "v2", name + ".npz"), allow_pickle=False)
+
+
 def load_case(name):
     sub = "ctc" if name.startswith("ctc_") else ""
     z = np.load(os.path.join(GOLDEN_DIR, sub, name + ".npz"), allow_pickle=False)

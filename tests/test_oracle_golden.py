@@ -4,7 +4,7 @@ import pytest
 import torch
 
 from oracle import ref_model as R
-from tests._util import CASES, load_case, params_of, rel_err, greedy_raw_from_table
+from tests._util import CASES, V2_CASES, V2_RUNS, load_case, load_v2, params_of, rel_err, greedy_raw_from_table
 
 
 @pytest.mark.parametrize("name", CASES)
@@ -110,3 +110,41 @@ def test_beam_tokens(name):
                 want = [int(v) for v in table[eos] if v >= 0]
                 got, _ = m.decoder.decode_beam(hb, lengths[utt:utt + 1], width, max_len, eos, score)
                 assert got == want, (tag, utt, eos)
+
+
+@pytest.mark.parametrize("name", V2_CASES)
+def test_beam_v2_tokens(name):
+    """The oracle's decode_beam_v2 against what the reference's decode_v2() returned (widths 3 and 4
+    with the log_softmax score, 2 and 6 with the softmax score), for every eos id -- including the
+    searches whose answer is [] because an empty result slot wins the final argmax."""
+    z, hp = load_case(name)
+    v2 = load_v2(name)
+    m = R.AttModel(hp)
+    m.load_state_dict(params_of(z))
+    m.eval()
+    x = torch.from_numpy(z["x"])
+    lengths = torch.from_numpy(z["lengths"])
+    max_len = int(v2["max_len"])
+    seen = 0
+    for tag, width, score in V2_RUNS:
+        for utt in range(2):
+            if f"{tag}.utt{utt}" not in v2.files:
+                continue
+            table = v2[f"{tag}.utt{utt}"]
+            hb = m.encoder(x[utt:utt + 1], lengths[utt:utt + 1])
+            for eos in range(hp.num_classes):
+                want = [int(v) for v in table[eos] if v >= 0]
+                got, _ = m.decoder.decode_beam_v2(hb, lengths[utt:utt + 1], width, max_len, eos, score)
+                assert got == want, (tag, utt, eos)
+                seen += bool(want)
+    assert seen > 0
+
+
+def test_beam_v2_rejects_unequal_widths():
+    """decoder.py:219,241: the reference raises when 2 * decoder width != encoder output width."""
+    z, hp = load_case("mixed_h")
+    m = R.AttModel(hp)
+    m.load_state_dict(params_of(z))
+    hb = m.encoder(torch.from_numpy(z["x"])[:1], torch.from_numpy(z["lengths"])[:1])
+    with pytest.raises(RuntimeError):
+        m.decoder.decode_beam_v2(hb, torch.from_numpy(z["lengths"])[:1], 3, 5, 1)
