@@ -2,7 +2,8 @@
 
     model = AttModel(hp)
     youtput = model(x, lengths, targets)        # (B,L,V), differentiable
-    tokens  = model.decode(x, lengths)          # greedy, batch 1
+    tokens  = model.decode(x, lengths)          # greedy / beam search, batch 1
+    tokens  = model.decode_v2(x, lengths)       # the second beam search, batch 1
 
 ``forward(x, lengths, targets, src_pos=None)`` keeps the reference's argument
 meaning: x (B,T,D) fp32 on the GPU (already frame-stacked), lengths (B,) int64
@@ -44,3 +45,11 @@ class AttModel(nn.Module):
         with torch.no_grad():
             hbatch = self.encoder(x, lengths)
             return self.decoder.decode(hbatch, lengths, None)
+
+    def decode_v2(self, x, lengths, model_lm=None, src_pos=None):
+        """Models/AttModel.py:41-49."""
+        if model_lm is not None:
+            raise NotImplementedError("asr_amd.AttModel.decode_v2: LM shallow fusion is outside the path")
+        with torch.no_grad():
+            hbatch = self.encoder(x, lengths)
+            return self.decoder.decode_v2(hbatch, lengths, None)

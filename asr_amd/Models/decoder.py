@@ -218,6 +218,19 @@ class Decoder(nn.Module):
         return self.decode_raw(hbatch, lengths)[0]
 
     @torch.no_grad()
+    def decode_v2(self, hbatch, lengths, model_lm=None):
+        """Models/decoder.py:132-267 (batch 1, no LM): the second beam search -- finished
+        hypotheses are collected in ``hp.beam_width`` result slots and the best-scoring slot is
+        returned (see ``beam.beam_decode_v2`` for the rules, including when [] comes back).  The
+        reference's trailing matplotlib / sentencepiece imports (:261-264) have no effect on the
+        result and are not mirrored."""
+        if model_lm is not None:
+            raise NotImplementedError("asr_amd.Decoder.decode_v2: LM shallow fusion is outside the path")
+        from .beam import beam_decode_v2
+        return beam_decode_v2(self, hbatch, lengths, int(self.hp.beam_width), self.hp.max_decoder_seq_len,
+                              self.hp.eos_id, getattr(self.hp, "score_func", "log_softmax"))[0]
+
+    @torch.no_grad()
     def decode_raw(self, hbatch, lengths):
         assert hbatch.shape[0] == 1, "greedy decode is batch-1, as in the reference"
         from .greedy import greedy_decode

@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 import torch
 
-from tests._util import CASES, load_case, params_of, rel_err, greedy_raw_from_table
+from tests._util import CASES, V2_CASES, V2_RUNS, load_case, load_v2, params_of, rel_err, greedy_raw_from_table
 
 pytestmark = pytest.mark.gpu
 
@@ -659,6 +659,77 @@ def test_golden_beam_tokens(name):
         hp.eos_id = eos
         got = m.decode(x[0:1].to(dev), lengths[0:1])
         assert got == [int(v) for v in table[eos] if v >= 0]
+
+
+@pytest.mark.parametrize("name", V2_CASES)
+def test_golden_beam_v2_tokens(name):
+    """decode_v2 (Models/decoder.py:132-267) on the device kernels: token-identical to what the
+    reference's decode_v2() returned for every eos id (widths 3 and 4 / log_softmax, 2 and 6 /
+    softmax; [] where an empty result slot wins), and with an eos id that never occurs the live
+    hypotheses of every step equal the oracle's (same sequences, same order, scores to 1e-4)."""
+    from asr_amd.Models.beam import beam_decode_v2
+    from oracle import ref_model as R
+    z, hp = load_case(name)
+    v2 = load_v2(name)
+    dev = _dev()
+    m = _build(hp, params_of(z)).eval()
+    ref = R.AttModel(hp)
+    ref.load_state_dict(params_of(z))
+    ref.eval()
+    x = torch.from_numpy(z["x"])
+    lengths = torch.from_numpy(z["lengths"])
+    max_len = int(v2["max_len"])
+    for tag, width, score in V2_RUNS:
+        for utt in range(2):
+            if f"{tag}.utt{utt}" not in v2.files:
+                continue
+            table = v2[f"{tag}.utt{utt}"]
+            with torch.no_grad():
+                hb = m.encoder(x[utt:utt + 1].to(dev), lengths[utt:utt + 1])
+                hr = ref.encoder(x[utt:utt + 1], lengths[utt:utt + 1])
+            _, trace = beam_decode_v2(m.decoder, hb, lengths[utt:utt + 1], width, max_len, -1, score)
+            _, want_trace = ref.decoder.decode_beam_v2(hr, lengths[utt:utt + 1], width, max_len, -1, score)
+            assert len(trace) == len(want_trace) == max_len
+            for (got_live, _), (want_live, _) in zip(trace, want_trace):
+                assert [s_ for s_, _ in got_live] == [s_ for s_, _ in want_live]
+                for (_, a_), (_, b_) in zip(got_live, want_live):
+                    assert abs(a_ - b_) < 1e-4 * max(1.0, abs(b_))
+            for eos in range(hp.num_classes):
+                want = [int(v) for v in table[eos] if v >= 0]
+                got, _ = beam_decode_v2(m.decoder, hb, lengths[utt:utt + 1], width, max_len, eos, score)
+                assert got == want, (tag, utt, eos)
+    # through the module interface (hp.beam_width, hp.score_func, hp.eos_id, hp.max_decoder_seq_len)
+    hp.beam_width, hp.score_func, hp.max_decoder_seq_len = 3, "log_softmax", max_len
+    table = v2["v2beam3.utt0"]
+    for eos in range(hp.num_classes):
+        hp.eos_id = eos
+        assert m.decode_v2(x[0:1].to(dev), lengths[0:1]) == [int(v) for v in table[eos] if v >= 0]
+
+
+def test_beam_v2_errors():
+    """The reference raises RuntimeError for unequal encoder/decoder widths (decoder.py:219,241)
+    and for widths its topk calls reject; LM fusion is outside the path."""
+    from asr_amd.Models.beam import beam_decode_v2
+    z, hp = load_case("mixed_h")
+    dev = _dev()
+    m = _build(hp, params_of(z)).eval()
+    x = torch.from_numpy(z["x"])[:1].to(dev)
+    lengths = torch.from_numpy(z["lengths"])[:1]
+    with torch.no_grad():
+        hb = m.encoder(x, lengths)
+    with pytest.raises(RuntimeError):
+        beam_decode_v2(m.decoder, hb, lengths, 3, 5, 1)
+    z, hp = load_case("tiny_a")
+    m = _build(hp, params_of(z)).eval()
+    x = torch.from_numpy(z["x"])[:1].to(dev)
+    lengths = torch.from_numpy(z["lengths"])[:1]
+    with torch.no_grad():
+        hb = m.encoder(x, lengths)
+    for width in (1, hp.num_classes + 1):
+        with pytest.raises(RuntimeError):
+            beam_decode_v2(m.decoder, hb, lengths, width, 5, 1)
+    with pytest.raises(NotImplementedError):
+        m.decode_v2(x, lengths, model_lm=object())
 
 
 # ------------------------------------------------ optimizer step (SURVEY 8f rank 1) --
