@@ -1,4 +1,4 @@
-"""Drop-in for Models/AttModel.py:10-39 (BLSTM-encoder branch) on the HIP kernels.
+"""Drop-in for Models/AttModel.py:10-49 (BLSTM and Conformer encoder branches) on the HIP kernels.
 
     model = AttModel(hp)
     youtput = model(x, lengths, targets)        # (B,L,V), differentiable
@@ -17,6 +17,7 @@ import torch.nn as nn
 from ..utils.utils import lengths_to_device
 from .decoder import Decoder
 from .encoder import Encoder
+from .Transformer_encoder import TransformerEncoder
 
 
 class AttModel(nn.Module):
@@ -24,26 +25,40 @@ class AttModel(nn.Module):
         super().__init__()
         self.hp = hp
         enc = getattr(hp, "encoder_type", None)
-        if enc is not None and enc != "BLSTM":
+        if enc == "Wave":
             raise NotImplementedError(
-                f"asr_amd.AttModel: encoder_type={enc!r} is outside the accelerated path "
-                "(SURVEY.md section 8: BLSTM encoder only)")
+                "asr_amd.AttModel: encoder_type='Wave' is outside the accelerated path "
+                "(SURVEY.md section 8: BLSTM and Conformer encoders)")
         # construction order = the reference's (encoder, then decoder) so a seeded
         # default init draws the same random numbers
-        self.encoder = Encoder(hp)
+        if enc == "Conformer":
+            self.encoder = TransformerEncoder(hp.lmfb_dim, 256, 16, 4, 0.1)     # Models/AttModel.py:17
+        else:
+            self.encoder = Encoder(hp)
         self.decoder = Decoder(hp)
+
+    def _encode(self, x, lengths, src_pos):
+        if getattr(self.hp, "encoder_type", None) == "Conformer":
+            # Models/AttModel.py:23-27: the decoder receives the *un-subsampled* lengths, so its frame
+            # mask is all ones wherever they exceed the subsampled length (the kernels clamp to T)
+            return self.encoder(x, src_pos)
+        return None
 
     def forward(self, x, lengths, targets, src_pos=None):
         # one asynchronous host -> device hand-over of the lengths for both halves of the model
         lengths_dev = lengths_to_device(lengths, x.device)
-        hbatch = self.encoder(x, lengths_dev, lengths_host=None if lengths.is_cuda else lengths)
+        hbatch = self._encode(x, lengths, src_pos)
+        if hbatch is None:
+            hbatch = self.encoder(x, lengths_dev, lengths_host=None if lengths.is_cuda else lengths)
         return self.decoder(hbatch, lengths_dev, targets)
 
     def decode(self, x, lengths, model_lm=None, src_pos=None):
         if model_lm is not None:
             raise NotImplementedError("asr_amd.AttModel.decode: LM shallow fusion is outside the path")
         with torch.no_grad():
-            hbatch = self.encoder(x, lengths)
+            hbatch = self._encode(x, lengths, src_pos)
+            if hbatch is None:
+                hbatch = self.encoder(x, lengths)
             return self.decoder.decode(hbatch, lengths, None)
 
     def decode_v2(self, x, lengths, model_lm=None, src_pos=None):
@@ -51,5 +66,7 @@ class AttModel(nn.Module):
         if model_lm is not None:
             raise NotImplementedError("asr_amd.AttModel.decode_v2: LM shallow fusion is outside the path")
         with torch.no_grad():
-            hbatch = self.encoder(x, lengths)
+            hbatch = self._encode(x, lengths, src_pos)
+            if hbatch is None:
+                hbatch = self.encoder(x, lengths)
             return self.decoder.decode_v2(hbatch, lengths, None)

@@ -32,6 +32,7 @@ class GemmDesc(C.Structure):
         ("m_idx", c_f), ("k_idx", c_f),
         ("bias_d", C.c_int), ("bias1_s1", c_i64), ("bias2_s1", c_i64),
         ("c_keep", c_f), ("c_keep_scale", C.c_float),
+        ("batch_d", C.c_int), ("batch_a1", c_i64), ("batch_b1", c_i64), ("batch_c1", c_i64),
     ]
 
 
@@ -106,6 +107,31 @@ SYMBOLS = {
     "asr_attdec_step_cell": (C.c_int, [C.POINTER(AttDecFwdArgs), c_f]),
     "asr_attdec_bwd_ws_floats": (c_i64, [C.c_int] * 5),
     "asr_attdec_bwd": (C.c_int, [C.POINTER(AttDecBwdArgs), c_f]),
+    # Conformer encoder (csrc/conformer.hip)
+    "asr_layernorm_fwd": (C.c_int, [c_f] * 6 + [c_i64, C.c_int, C.c_float, c_f]),
+    "asr_layernorm_bwd_blocks": (c_i64, [c_i64]),
+    "asr_layernorm_bwd": (C.c_int, [c_f] * 7 + [c_i64, C.c_int, C.c_int, c_f]),
+    "asr_swish_fwd": (C.c_int, [c_f, c_f, c_i64, c_f]),
+    "asr_swish_bwd": (C.c_int, [c_f, c_f, c_f, c_i64, c_f]),
+    "asr_glu_fwd": (C.c_int, [c_f, c_f, c_i64, C.c_int, c_f]),
+    "asr_glu_bwd": (C.c_int, [c_f, c_f, c_f, c_i64, C.c_int, c_f]),
+    "asr_relu_bwd": (C.c_int, [c_f, c_f, c_f, c_i64, c_f]),
+    "asr_axpby": (C.c_int, [c_f, c_f, c_f, c_i64, C.c_float, C.c_float, c_f]),
+    "asr_add_two_bias": (C.c_int, [c_f] * 5 + [c_i64, C.c_int, c_f]),
+    "asr_dwconv": (C.c_int, [c_f] * 4 + [C.c_int] * 5 + [c_f]),
+    "asr_dwconv_bwd_w_chunks": (c_i64, [C.c_int, C.c_int]),
+    "asr_dwconv_bwd_w": (C.c_int, [c_f] * 3 + [C.c_int] * 4 + [c_f]),
+    "asr_bn_blocks": (c_i64, [c_i64]),
+    "asr_bn_var_part": (C.c_int, [c_f, c_f, C.c_float, c_f, c_i64, C.c_int, c_f]),
+    "asr_bn_swish_fwd": (C.c_int, [c_f, c_f, c_f, C.c_float, C.c_float, c_f, c_f, c_f, c_i64, C.c_int, C.c_float, c_f]),
+    "asr_bn_swish_bwd_part": (C.c_int, [c_f, c_f, c_f, c_f, C.c_float, C.c_float, c_f, c_f, c_f, c_i64, C.c_int,
+                                        C.c_float, c_f]),
+    "asr_bn_swish_bwd": (C.c_int, [c_f, c_f, c_f, c_f, C.c_float, C.c_float, c_f, c_f, c_f, c_f, c_i64, C.c_int,
+                                   C.c_float, c_f]),
+    "asr_relattn_softmax_fwd": (C.c_int, [c_f, c_f, c_f, C.c_float, C.c_int, C.c_int, C.c_int, c_f]),
+    "asr_relattn_softmax_bwd": (C.c_int, [c_f, c_f, c_f, c_f, C.c_float, C.c_int, C.c_int, C.c_int, c_f]),
+    "asr_im2col_3x3s2": (C.c_int, [c_f, c_f, C.c_int, C.c_int, C.c_int, C.c_int, c_f]),
+    "asr_col2im_3x3s2": (C.c_int, [c_f, c_f, C.c_int, C.c_int, C.c_int, C.c_int, c_f]),
 }
 
 _lib = None

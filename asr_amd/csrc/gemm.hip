@@ -171,9 +171,11 @@ __global__ __launch_bounds__(256) void sgemm_kernel(asr_gemm_desc d, int vecA, i
     const int n0 = blockIdx.x * BN, m0 = blockIdx.y * BM;
     const int batch = blockIdx.z / d.splitk, split = blockIdx.z % d.splitk;
 
-    OperandView va{d.A + (int64_t)batch * d.batch_a, d.a_mode, d.a_s0, d.a_s1, d.a_d};
-    OperandView vb{d.B + (int64_t)batch * d.batch_b, d.b_mode, d.b_s0, d.b_s1, d.b_d};
-    float *C = d.C + (int64_t)batch * d.batch_c;
+    // two-level batch index (batch_d > 0): (batch / batch_d, batch % batch_d) -- e.g. (utterance, head)
+    const int bhi = d.batch_d > 0 ? batch / d.batch_d : 0, blo = batch - bhi * (d.batch_d > 0 ? d.batch_d : 0);
+    OperandView va{d.A + (int64_t)blo * d.batch_a + (int64_t)bhi * d.batch_a1, d.a_mode, d.a_s0, d.a_s1, d.a_d};
+    OperandView vb{d.B + (int64_t)blo * d.batch_b + (int64_t)bhi * d.batch_b1, d.b_mode, d.b_s0, d.b_s1, d.b_d};
+    float *C = d.C + (int64_t)blo * d.batch_c + (int64_t)bhi * d.batch_c1;
 
     const int kbeg = split * ktiles_per_split * GK;
     const int kend = min(d.K, kbeg + ktiles_per_split * GK);
@@ -275,7 +277,8 @@ __global__ __launch_bounds__(256) void sgemm_kernel(asr_gemm_desc d, int vecA, i
                 } else {
                     if (d.accumulate) v += *dst;
                     if (d.act == 1) v = tanh_f(v);
-                    if (d.c_keep) v = d.c_keep[(dst - d.C)] ? v * d.c_keep_scale : 0.f;
+                    else if (d.act == 2) v = fmaxf(v, 0.f);
+                    if (d.c_keep) v = d.c_keep[(dst - d.C)] ? v * d.c_keep_scale : 0.f;   // nbatch == 1
                     *dst = v;
                 }
             }
@@ -298,7 +301,8 @@ extern "C" int asr_sgemm(const asr_gemm_desc *din, void *stream) {
     if (d.b_d <= 0) d.b_d = 0x7fffffff;
     if (d.c_d <= 0) d.c_d = 0x7fffffff;
     ASR_CHECK_ARG(!(d.splitk > 1 && d.act != 0), "sgemm: activation needs splitk == 1");
-    ASR_CHECK_ARG(d.act == 0 || d.act == 1, "sgemm: bad act %d", d.act);
+    ASR_CHECK_ARG(d.act >= 0 && d.act <= 2, "sgemm: bad act %d", d.act);
+    ASR_CHECK_ARG(d.batch_d >= 0, "sgemm: negative batch_d");
     ASR_CHECK_ARG(!d.m_idx || (d.a_mode == 0 && d.nbatch == 1), "sgemm: m_idx needs a_mode 0 and nbatch 1");
     ASR_CHECK_ARG(!d.k_idx || (d.a_mode == 1 && d.b_mode == 1 && d.nbatch == 1),
                   "sgemm: k_idx needs a_mode 1, b_mode 1 and nbatch 1");
@@ -310,8 +314,11 @@ extern "C" int asr_sgemm(const asr_gemm_desc *din, void *stream) {
     auto strides_ok = [&](int64_t s0, int64_t s1, int64_t sb) {
         return (s0 % 4 == 0) && (s1 % 4 == 0 || s1 == 0) && (sb % 4 == 0);
     };
-    const int vecA = aligned16(d.A) && strides_ok(d.a_s0, d.a_s1, d.nbatch > 1 ? d.batch_a : 0);
-    const int vecB = aligned16(d.B) && strides_ok(d.b_s0, d.b_s1, d.nbatch > 1 ? d.batch_b : 0);
+    const bool two = d.nbatch > 1 && d.batch_d > 0;
+    const int vecA = aligned16(d.A) && strides_ok(d.a_s0, d.a_s1, d.nbatch > 1 ? d.batch_a : 0) &&
+                     (!two || d.batch_a1 % 4 == 0);
+    const int vecB = aligned16(d.B) && strides_ok(d.b_s0, d.b_s1, d.nbatch > 1 ? d.batch_b : 0) &&
+                     (!two || d.batch_b1 % 4 == 0);
 
     const int64_t tiles128 = (int64_t)cdiv(d.M, 128) * cdiv(d.N, 128) * d.nbatch * (d.splitk > 0 ? d.splitk : 1);
     const bool big = d.M >= 128 && d.N >= 128 && tiles128 >= 128;

@@ -127,7 +127,7 @@ typedef struct {
     const float *bias1, *bias2;
     float alpha;
     int accumulate;     /* C += result (read-modify-write) */
-    int act;            /* 0 none, 1 tanh applied to the stored value (splitk must be 1) */
+    int act;            /* 0 none, 1 tanh, 2 relu applied to the stored value (splitk must be 1) */
     int splitk;
     int nbatch;
     int64_t batch_a, batch_b, batch_c;
@@ -142,6 +142,12 @@ typedef struct {
      * GEMM's consumer (nn.LSTM(dropout=p), Models/encoder.py:26), fused into the dX epilogue */
     const uint8_t *c_keep;
     float c_keep_scale;
+    /* batch_d > 0: two-level batch index; batch n addresses operand X at
+     * X + (n % batch_d) * batch_x + (n / batch_d) * batch_x1 -- the (utterance, head) pairs of the
+     * relative-position attention (Models/Transformer_encoder.py:97-98,136), whose heads are
+     * interleaved inside the (B, T, heads * d_k) projections */
+    int batch_d;
+    int64_t batch_a1, batch_b1, batch_c1;
 } asr_gemm_desc;
 
 int asr_sgemm(const asr_gemm_desc *d, void *stream);
@@ -260,6 +266,65 @@ int asr_dropout_bwd(const float *dy, const uint8_t *mask, float *dx, int64_t n, 
  * would give it. */
 int asr_dropout_fwd_block(const float *x, float *y, uint8_t *mask, int64_t rows, int64_t cols, int64_t ld,
                           int64_t first, float p, uint64_t seed, void *stream);
+
+/* ------------------------------------------ Conformer encoder (next, 8f rank 3) --
+ * Models/Transformer_encoder.py:441-451 (TransformerEncoder = CNN_embedding + ConformerEncoder),
+ * entered at Models/AttModel.py:17,24.  Activations are (B, T, C) row-major throughout.  The matrix
+ * products (every nn.Linear, the 1x1 Conv1d, the attention products, the Conv2d as col @ W^T) are
+ * asr_sgemm calls; these entry points are the rest. */
+/* nn.LayerNorm(d) (:161,194,218,250), d <= 1024: y, and per row mean / rstd for the backward */
+int asr_layernorm_fwd(const float *x, const float *gamma, const float *beta, float *y, float *mean,
+                      float *rstd, int64_t rows, int d, float eps, void *stream);
+/* dx (+)= its gradient; part[asr_layernorm_bwd_blocks(rows)][2][d] = per-block sums of dy*xhat
+ * (d gamma) and dy (d beta), to be summed with asr_colsum (deterministic) */
+int64_t asr_layernorm_bwd_blocks(int64_t rows);
+int asr_layernorm_bwd(const float *dy, const float *x, const float *gamma, const float *mean,
+                      const float *rstd, float *dx, float *part, int64_t rows, int d, int accumulate,
+                      void *stream);
+/* Swish (:175-177), GLU over the halves of a (rows, 2d) tensor (:232-233), ReLU gradient (:391-394),
+ * out = a*x + b*y (residuals :259,263-265; running statistics), qu = q + u / qv = q + v (:94-95) */
+int asr_swish_fwd(const float *x, float *y, int64_t n, void *stream);
+int asr_swish_bwd(const float *dy, const float *x, float *dx, int64_t n, void *stream);
+int asr_glu_fwd(const float *x, float *y, int64_t rows, int d, void *stream);
+int asr_glu_bwd(const float *dy, const float *x, float *dx, int64_t rows, int d, void *stream);
+int asr_relu_bwd(const float *dy, const float *y, float *dx, int64_t n, void *stream);
+int asr_axpby(const float *x, const float *y, float *out, int64_t n, float a, float b, void *stream);
+int asr_add_two_bias(const float *q, const float *u, const float *v, float *qu, float *qv, int64_t rows,
+                     int d, void *stream);
+/* DepthwiseConv.conv (:183,187-188): y[b,t,c] = bias[c] + sum_k w[c,k] x[b,t+k-15,c], K = 31;
+ * flip != 0 (bias NULL) gives the data gradient.  asr_dwconv_bwd_w writes
+ * part[asr_dwconv_bwd_w_chunks(B,T)][K][C], to be summed with asr_colsum into d w as (K, C). */
+int asr_dwconv(const float *x, const float *w, const float *bias, float *y, int B, int T, int C, int K,
+               int flip, void *stream);
+int64_t asr_dwconv_bwd_w_chunks(int B, int T);
+int asr_dwconv_bwd_w(const float *dy, const float *x, float *part, int B, int T, int C, int K, void *stream);
+/* nn.BatchNorm1d (:223,235) + Swish (:236) over rows = B*T frames.  msum / vsum: per-channel sum of
+ * x and of (x - mean)^2 with multipliers ms / vs (training: 1/rows; eval: the running mean / var with
+ * multipliers 1).  asr_bn_var_part and asr_bn_swish_bwd_part write asr_bn_blocks(rows) partial rows
+ * (C resp. 2C wide: sum du, sum du*xhat = d beta, d gamma) for asr_colsum.  sums == NULL: eval mode. */
+int64_t asr_bn_blocks(int64_t rows);
+int asr_bn_var_part(const float *x, const float *msum, float ms, float *part, int64_t rows, int C, void *stream);
+int asr_bn_swish_fwd(const float *x, const float *msum, const float *vsum, float ms, float vs,
+                     const float *gamma, const float *beta, float *y, int64_t rows, int C, float eps,
+                     void *stream);
+int asr_bn_swish_bwd_part(const float *dy, const float *x, const float *msum, const float *vsum, float ms,
+                          float vs, const float *gamma, const float *beta, float *part, int64_t rows, int C,
+                          float eps, void *stream);
+int asr_bn_swish_bwd(const float *dy, const float *x, const float *msum, const float *vsum, float ms, float vs,
+                     const float *gamma, const float *beta, const float *sums, float *dx, int64_t rows,
+                     int C, float eps, void *stream);
+/* RelativeMultiHeadAttention (:99-102,110-137): ac (B,H,T,T) becomes
+ * softmax_j(keep[b,j] ? (ac + rel_shift(bd)) * scale : -1e4) in place, T <= 1024.  Backward: dattn
+ * becomes d ac (= the shifted score gradient) in place and dbd its un-shifted copy. */
+int asr_relattn_softmax_fwd(float *ac, const float *bd, const uint8_t *keep, float scale, int B, int H, int T,
+                            void *stream);
+int asr_relattn_softmax_bwd(const float *attn, float *dattn, float *dbd, const uint8_t *keep, float scale,
+                            int B, int H, int T, void *stream);
+/* CNN_embedding (:386-407): patches of nn.Conv2d(Cin, Cout, 3, 2) on a channels-last map
+ * x (B,Ti,Fi,Cin): col (B*To*Fo, 9*Cin) in (ki,kj,cin) order, To = (Ti-3)/2+1, Fo = (Fi-3)/2+1;
+ * asr_col2im_3x3s2 is the data gradient (a gather, deterministic). */
+int asr_im2col_3x3s2(const float *x, float *col, int B, int Ti, int Fi, int Cin, void *stream);
+int asr_col2im_3x3s2(const float *dcol, float *dx, int B, int Ti, int Fi, int Cin, void *stream);
 
 /* ------------------------------------------------- attention decoder loop --
  * Replaces the L-step teacher-forced loop Models/decoder.py:52-60 with

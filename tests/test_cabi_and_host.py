@@ -76,7 +76,13 @@ def test_no_cpu_fallback():
     with pytest.raises(RuntimeError):
         label_smoothing_loss(torch.zeros(1, 2, 5), torch.zeros(1, 2, dtype=torch.long), torch.tensor([2]))
     with pytest.raises(NotImplementedError):
-        AttModel(R.make_hp(encoder_type="Conformer"))
+        AttModel(R.make_hp(encoder_type="Wave"))
+    # the Conformer branch (Models/AttModel.py:16-17): same module tree as the reference, no CPU path
+    from asr_amd.Models.Transformer_encoder import TransformerEncoder
+    enc = TransformerEncoder(20, 16, 1, 2, 0.0)
+    assert len(enc.state_dict()) == 45
+    with pytest.raises(RuntimeError):
+        enc(torch.zeros(1, 30, 20), torch.ones(1, 30, dtype=torch.long))
 
 
 def test_frame_stacking_matches_oracle():

@@ -1,0 +1,108 @@
+"""GPU parity of the Conformer encoder through the C ABI: asr_amd.Models.Transformer_encoder
+against the golden vectors produced by the reference's Models/Transformer_encoder.py and, at production
+widths, against the CPU restatement.  Bar: outputs 1e-4, gradients 1e-3 (max-abs error relative to the
+max-abs value; gradients that are zero in exact arithmetic are judged against 5 % of the largest one)."""
+import numpy as np
+import pytest
+import torch
+
+from tests._util import rel_err
+from tests.test_conformer_oracle import CONF_CASES, conf_state, grad_err, grad_floor, load_conf
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev():
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    return torch.device("cuda:0")
+
+
+def _build(meta, state, dropout=0.0):
+    from asr_amd.Models.Transformer_encoder import TransformerEncoder
+    m = TransformerEncoder(meta["idim"], meta["d_model"], meta["N_e"], meta["heads"], dropout)
+    m.load_state_dict(state)
+    return m.to(_dev())
+
+
+@pytest.mark.parametrize("name", CONF_CASES)
+def test_golden_conformer(name):
+    z, meta = load_conf(name)
+    dev = _dev()
+    m = _build(meta, conf_state(z))
+    assert sorted(m.state_dict().keys()) == sorted(k[len("param."):] for k in z.files if k.startswith("param."))
+    src = torch.from_numpy(z["src"]).to(dev)
+    src_pos = torch.from_numpy(z["src_pos"]).to(dev)
+    m.eval()
+    with torch.no_grad():
+        assert rel_err(m(src, src_pos).cpu(), z["f32.eval_out"]) < 1e-4
+    m.train()
+    y = m(src, src_pos)
+    assert rel_err(y.detach().cpu(), z["f32.train_out"]) < 1e-4
+    (y * torch.from_numpy(z["R"]).to(dev)).sum().backward()
+    floor = grad_floor(z, "f32")
+    for k, p in m.named_parameters():
+        assert p.grad is not None, k
+        assert grad_err(p.grad.cpu(), z[f"f32.grad.{k}"], floor) < 1e-3, k
+    for k, v in m.state_dict().items():
+        if "running_" in k:
+            assert rel_err(v.cpu(), z[f"f32.after.{k}"]) < 1e-5, k
+        if "num_batches" in k:
+            assert int(v) == int(z[f"f32.after.{k}"])
+
+
+def test_production_widths_vs_oracle():
+    """d_model 256, 4 heads, 80-dim features (AttModel.py:17) with 2 layers, ragged batch: output, all
+    gradients and BatchNorm statistics against the CPU restatement."""
+    from oracle import ref_conformer as RC
+    dev = _dev()
+    torch.manual_seed(7)
+    ref = RC.TransformerEncoder(80, 256, 2, 4, 0.0)
+    with torch.no_grad():
+        for k, p in ref.named_parameters():
+            if "norm" in k:
+                p.add_(0.1 * torch.randn_like(p))
+    B, T, lens = 3, 423, [423, 300, 171]
+    src = torch.randn(B, T, 80)
+    src_pos = torch.zeros(B, T, dtype=torch.int64)
+    for b, n in enumerate(lens):
+        src[b, n:] = 0
+        src_pos[b, :n] = torch.arange(1, n + 1)
+    m = _build(dict(idim=80, d_model=256, N_e=2, heads=4), ref.state_dict())
+    ref.train()
+    m.train()
+    yr = ref(src, src_pos)
+    R = torch.randn_like(yr)
+    (yr * R).sum().backward()
+    y = m(src.to(dev), src_pos.to(dev))
+    assert y.shape == yr.shape == (B, 105, 256)
+    assert rel_err(y.detach().cpu(), yr.detach()) < 1e-4
+    (y * R.to(dev)).sum().backward()
+    want = dict(ref.named_parameters())
+    floor = 5e-2 * max(float(p.grad.abs().max()) for p in want.values())
+    for k, p in m.named_parameters():
+        assert grad_err(p.grad.cpu(), want[k].grad, floor) < 1e-3, k
+    for k, v in m.state_dict().items():
+        if "running_" in k:
+            assert rel_err(v.cpu(), ref.state_dict()[k]) < 1e-5, k
+
+
+def test_dropout_modes_and_errors():
+    """Training with dropout 0.1 differs from eval and stays finite with finite gradients; eval is
+    deterministic; CPU input raises."""
+    z, meta = load_conf("conf_tiny")
+    dev = _dev()
+    m = _build(meta, conf_state(z), dropout=0.1)
+    src = torch.from_numpy(z["src"]).to(dev)
+    src_pos = torch.from_numpy(z["src_pos"]).to(dev)
+    m.eval()
+    with torch.no_grad():
+        a, b = m(src, src_pos), m(src, src_pos)
+    assert torch.equal(a, b)
+    m.train()
+    y = m(src, src_pos)
+    assert torch.isfinite(y).all() and not torch.equal(y.detach(), a)
+    y.sum().backward()
+    for k, p in m.named_parameters():
+        assert p.grad is not None and torch.isfinite(p.grad).all(), k
+    with pytest.raises(RuntimeError):
+        m(src.cpu(), src_pos.cpu())
