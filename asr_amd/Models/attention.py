@@ -14,7 +14,7 @@ class Attention(nn.Module):
         self.num_decoder_hidden_nodes = hp.num_hidden_nodes_decoder
         self.num_encoder_hidden_nodes = hp.num_hidden_nodes_encoder
         hd = hp.num_hidden_nodes_decoder
-        he = hp.num_hidden_nodes_encoder * 2
+        he = hp.num_hidden_nodes_encoder * (1 if getattr(hp, "encoder_type", None) == "Conformer" else 2)   # attention.py:13-16, decoder.py:19-22
         # same construction order as the reference so a seeded init matches it
         self.L_se = nn.Linear(hd, hd * 2, bias=False)
         self.L_he = nn.Linear(he, hd * 2)

@@ -173,7 +173,7 @@ class Decoder(nn.Module):
         super().__init__()
         self.hp = hp
         hd = hp.num_hidden_nodes_decoder
-        he = hp.num_hidden_nodes_encoder * 2
+        he = hp.num_hidden_nodes_encoder * (1 if getattr(hp, "encoder_type", None) == "Conformer" else 2)   # attention.py:13-16, decoder.py:19-22
         self.num_decoder_hidden_nodes = hd
         self.num_encoder_hidden_nodes = hp.num_hidden_nodes_encoder
         self.num_classes = hp.num_classes

@@ -109,7 +109,7 @@ class Attention(nn.Module):
     def __init__(self, hp):
         super().__init__()
         hd = hp.num_hidden_nodes_decoder
-        he = hp.num_hidden_nodes_encoder * 2
+        he = hp.num_hidden_nodes_encoder * (1 if getattr(hp, "encoder_type", None) == "Conformer" else 2)   # attention.py:13-16, decoder.py:19-22
         self.L_se = nn.Linear(hd, hd * 2, bias=False)
         self.L_he = nn.Linear(he, hd * 2)
         self.L_ee = nn.Linear(hd * 2, 1, bias=False)
@@ -146,7 +146,7 @@ class Decoder(nn.Module):
         super().__init__()
         self.hp = hp
         hd = hp.num_hidden_nodes_decoder
-        he = hp.num_hidden_nodes_encoder * 2
+        he = hp.num_hidden_nodes_encoder * (1 if getattr(hp, "encoder_type", None) == "Conformer" else 2)   # attention.py:13-16, decoder.py:19-22
         self.hd = hd
         self.att = Attention(hp)
         self.L_sy = nn.Linear(hd, hd, bias=False)

@@ -106,3 +106,56 @@ def test_dropout_modes_and_errors():
         assert p.grad is not None and torch.isfinite(p.grad).all(), k
     with pytest.raises(RuntimeError):
         m(src.cpu(), src_pos.cpu())
+
+
+def test_attmodel_conformer_branch_vs_oracle():
+    """AttModel(encoder_type='Conformer') (Models/AttModel.py:16-17,23-27: 16 layers, d_model 256, 4 heads,
+    the decoder fed the un-subsampled lengths) + label-smoothed CE: loss and every gradient against the CPU
+    restatements (Conformer encoder + attention decoder), dropout off so the training-mode pass is deterministic."""
+    import torch.nn as nn
+    from asr_amd.Loss.label_smoothing import label_smoothing_loss
+    from asr_amd.Models.AttModel import AttModel
+    from oracle import ref_conformer as RC
+    from oracle import ref_model as R
+    dev = _dev()
+    hp = R.make_hp(lmfb_dim=20, frame_stacking=1, num_hidden_nodes_encoder=256, num_hidden_nodes_decoder=24,
+                   num_classes=31, encoder_type="Conformer", encoder_dropout=0.0)
+    torch.manual_seed(3)
+    m = AttModel(hp)
+
+    class RefAtt(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.encoder = RC.TransformerEncoder(hp.lmfb_dim, 256, 16, 4, 0.0)
+            self.decoder = R.Decoder(hp)
+
+        def forward(self, x, lengths, targets, src_pos):
+            return self.decoder(self.encoder(x, src_pos), lengths, targets)
+
+    ref = RefAtt()
+    ref.load_state_dict(m.state_dict())
+    for mod in m.modules():
+        if hasattr(mod, "p"):
+            mod.p = 0.0
+    m = m.to(dev).train()
+    ref.train()
+    B, T, L, lens, tls = 2, 90, 4, [90, 61], [4, 2]
+    x = torch.randn(B, T, 20)
+    src_pos = torch.zeros(B, T, dtype=torch.int64)
+    for b, n in enumerate(lens):
+        x[b, n:] = 0
+        src_pos[b, :n] = torch.arange(1, n + 1)
+    targets = torch.randint(0, 31, (B, L))
+    lengths, tl = torch.tensor(lens), torch.tensor(tls)
+    yr = ref(x, lengths, targets, src_pos)
+    lr = R.label_smoothing_loss(yr, targets, tl)
+    lr.backward()
+    y = m(x.to(dev), lengths, targets.to(dev), src_pos.to(dev))
+    loss = label_smoothing_loss(y, targets.to(dev), tl.to(dev))
+    loss.backward()
+    assert rel_err(y.detach().cpu(), yr.detach()) < 1e-4
+    assert abs(float(loss) - float(lr)) / abs(float(lr)) < 1e-4
+    want = dict(ref.named_parameters())
+    floor = 5e-2 * max(float(p.grad.abs().max()) for p in want.values())
+    for k, p in m.named_parameters():
+        assert grad_err(p.grad.cpu(), want[k].grad, floor) < 1e-3, k
