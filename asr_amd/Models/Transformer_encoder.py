@@ -153,10 +153,16 @@ class _FFFunction(torch.autograd.Function):
 
 
 # ------------------------------------------------- relative-position attention block --
-def _head_gemm(A, Bm, Cm, M, N, K, H, nb, *, a, b, c, a_mode=0, b_mode=0):
+def _head_gemm(A, Bm, Cm, M, N, K, H, nb, *, a, b, c, a_mode=0, b_mode=0, pad_ok=0):
     """One product per (utterance, head): a / b / c = (row stride, per-head offset, per-utterance offset)."""
     ops.sgemm(A, Bm, Cm, M, N, K, a_mode=a_mode, b_mode=b_mode, a_stride=a[0], b_stride=b[0], c_stride=c[0],
-              nbatch=nb * H, batch_a=a[1], batch_b=b[1], batch_c=c[1], batch_two=(H, a[2], b[2], c[2]))
+              nbatch=nb * H, batch_a=a[1], batch_b=b[1], batch_c=c[1], batch_two=(H, a[2], b[2], c[2]), pad_ok=pad_ok)
+
+
+def _pad4(T):
+    """Row stride of the attention maps: the next multiple of 4, so the products that read them
+    column-wise (attn^T d ctx, d ac^T (q + u), d bd^T (q + v)) use 16-byte loads (asr_gemm_desc.pad_ok)."""
+    return (T + 3) // 4 * 4
 
 
 class _RelAttnFunction(torch.autograd.Function):
@@ -175,13 +181,14 @@ class _RelAttnFunction(torch.autograd.Function):
         pp = _linear(pe, wpos)                                              # (T, d), shared by the batch
         qu, qv = torch.empty_like(q), torch.empty_like(q)
         check(lib.asr_add_two_bias(q.data_ptr(), u.data_ptr(), v.data_ptr(), qu.data_ptr(), qv.data_ptr(), B * T, d, _st()))
-        proj, score, posp = (d, dk, T * d), (T, T * T, H * T * T), (d, dk, 0)
-        attn = _e(B, H, T, T, like=x)
-        bd = _e(B, H, T, T, like=x)
+        Tp = _pad4(T)
+        proj, score, posp = (d, dk, T * d), (Tp, T * Tp, H * T * Tp), (d, dk, 0)
+        attn = _e(B, H, T, Tp, like=x)
+        bd = _e(B, H, T, Tp, like=x)
         _head_gemm(qu, k, attn, T, T, dk, H, B, a=proj, b=proj, c=score)      # (q + u) k^T          :97
         _head_gemm(qv, pp, bd, T, T, dk, H, B, a=proj, b=posp, c=score)       # (q + v) p^T          :98
         scale = 1.0 / math.sqrt(dk)
-        check(lib.asr_relattn_softmax_fwd(attn.data_ptr(), bd.data_ptr(), keep.data_ptr(), C.c_float(scale), B, H, T, _st()))
+        check(lib.asr_relattn_softmax_fwd(attn.data_ptr(), bd.data_ptr(), keep.data_ptr(), C.c_float(scale), B, H, T, Tp, _st()))
         del bd
         attn_d, m_att = _drop(attn, p, training, seed)
         cx = _e(B * T, d, like=x)
@@ -198,26 +205,27 @@ class _RelAttnFunction(torch.autograd.Function):
         (x2, nw, wq, wk, wv, wpos, wo, pe, keep, mean, rstd, h, qu, qv, k, vv, pp, attn, attn_d, cx) = ctx.saved_tensors
         B, T, d, H, p, scale, m_att, m_o = ctx.aux
         dk = d // H
-        proj, score, posp = (d, dk, T * d), (T, T * T, H * T * T), (d, dk, 0)
+        Tp = _pad4(T)
+        proj, score, posp = (d, dk, T * d), (Tp, T * Tp, H * T * Tp), (d, dk, 0)
         dy2 = dy.contiguous().view_as(x2)
         do = _drop_bwd(dy2, m_o, p)
         dcx, dWo, dbo = _linear_bwd(do, cx, wo)
-        dattn = _e(B, H, T, T, like=x2)
+        dattn = _e(B, H, T, Tp, like=x2)
         _head_gemm(dcx, vv, dattn, T, T, dk, H, B, a=proj, b=proj, c=score)                       # d attn = d ctx v^T
         dvv = torch.empty_like(vv)
-        _head_gemm(attn_d, dcx, dvv, T, dk, T, H, B, a=score, b=proj, c=proj, a_mode=1, b_mode=1)  # d v = attn^T d ctx
+        _head_gemm(attn_d, dcx, dvv, T, dk, T, H, B, a=score, b=proj, c=proj, a_mode=1, b_mode=1, pad_ok=1)  # d v = attn^T d ctx
         dattn = _drop_bwd(dattn, m_att, p)
         dbd = torch.empty_like(dattn)
         check(lib.asr_relattn_softmax_bwd(attn.data_ptr(), dattn.data_ptr(), dbd.data_ptr(), keep.data_ptr(),
-                                          C.c_float(scale), B, H, T, _st()))
+                                          C.c_float(scale), B, H, T, Tp, _st()))
         dqu, dkk, dqv = torch.empty_like(qu), torch.empty_like(k), torch.empty_like(qv)
         _head_gemm(dattn, k, dqu, T, dk, T, H, B, a=score, b=proj, c=proj, b_mode=1)               # d ac k
-        _head_gemm(dattn, qu, dkk, T, dk, T, H, B, a=score, b=proj, c=proj, a_mode=1, b_mode=1)    # d ac^T (q + u)
+        _head_gemm(dattn, qu, dkk, T, dk, T, H, B, a=score, b=proj, c=proj, a_mode=1, b_mode=1, pad_ok=1)    # d ac^T (q + u)
         _head_gemm(dbd, pp, dqv, T, dk, T, H, B, a=score, b=posp, c=proj, b_mode=1)                # d bd p
         # d p[h] = sum_b d bd[b,h]^T (q + v)[b,:,h,:]: the reduction runs over (b, i) through a two-level row map
         dpp = torch.empty_like(pp)
-        ops.sgemm(dbd, qv, dpp, T, dk, B * T, a_mode=1, b_mode=1, a_two=(T, T, H * T * T), b_stride=d, c_stride=d,
-                  nbatch=H, batch_a=T * T, batch_b=dk, batch_c=dk)
+        ops.sgemm(dbd, qv, dpp, T, dk, B * T, a_mode=1, b_mode=1, a_two=(T, Tp, H * T * Tp), b_stride=d, c_stride=d,
+                  nbatch=H, batch_a=T * Tp, batch_b=dk, batch_c=dk, pad_ok=1)
         du, dv = _e(d, like=x2), _e(d, like=x2)
         ops.colsum(dqu, du)
         ops.colsum(dqv, dv)

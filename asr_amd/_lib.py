@@ -33,6 +33,7 @@ class GemmDesc(C.Structure):
         ("bias_d", C.c_int), ("bias1_s1", c_i64), ("bias2_s1", c_i64),
         ("c_keep", c_f), ("c_keep_scale", C.c_float),
         ("batch_d", C.c_int), ("batch_a1", c_i64), ("batch_b1", c_i64), ("batch_c1", c_i64),
+        ("pad_ok", C.c_int),
     ]
 
 
@@ -128,8 +129,8 @@ SYMBOLS = {
                                         C.c_float, c_f]),
     "asr_bn_swish_bwd": (C.c_int, [c_f, c_f, c_f, c_f, C.c_float, C.c_float, c_f, c_f, c_f, c_f, c_i64, C.c_int,
                                    C.c_float, c_f]),
-    "asr_relattn_softmax_fwd": (C.c_int, [c_f, c_f, c_f, C.c_float, C.c_int, C.c_int, C.c_int, c_f]),
-    "asr_relattn_softmax_bwd": (C.c_int, [c_f, c_f, c_f, c_f, C.c_float, C.c_int, C.c_int, C.c_int, c_f]),
+    "asr_relattn_softmax_fwd": (C.c_int, [c_f, c_f, c_f, C.c_float, C.c_int, C.c_int, C.c_int, C.c_int, c_f]),
+    "asr_relattn_softmax_bwd": (C.c_int, [c_f, c_f, c_f, c_f, C.c_float, C.c_int, C.c_int, C.c_int, C.c_int, c_f]),
     "asr_im2col_3x3s2": (C.c_int, [c_f, c_f, C.c_int, C.c_int, C.c_int, C.c_int, c_f]),
     "asr_col2im_3x3s2": (C.c_int, [c_f, c_f, C.c_int, C.c_int, C.c_int, C.c_int, c_f]),
 }

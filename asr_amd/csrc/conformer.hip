@@ -53,7 +53,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float *__restrict__ x
 
 // dx = rstd (gy - mean(gy) - xhat mean(gy xhat)), gy = dy gamma; per-block partial sums of
 // dy xhat (d gamma) and dy (d beta) go to part[block][2][d] for a deterministic second stage.
-#define LN_BWD_ROWS 64
+#define LN_BWD_ROWS 16
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const float *__restrict__ dy, const float *__restrict__ x,
                                                      const float *__restrict__ g, const float *__restrict__ mean,
                                                      const float *__restrict__ rstd, float *__restrict__ dx,
@@ -449,15 +449,15 @@ extern "C" int asr_bn_swish_bwd(const float *dy, const float *x, const float *ms
 #define SM_MAXV 16
 __global__ __launch_bounds__(256) void relattn_softmax_fwd_kernel(float *__restrict__ ac, const float *__restrict__ bd,
                                                                   const uint8_t *__restrict__ keep, float scale, int H,
-                                                                  int T, int64_t nrows) {
+                                                                  int T, int ld, int64_t nrows) {
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (row >= nrows) return;
     const int i = (int)(row % T);
     const int64_t bh = row / T;
     const int b = (int)(bh / H);
-    float *a = ac + row * T;
-    const float *m = bd + bh * (int64_t)T * T;
+    float *a = ac + row * ld;
+    const float *m = bd + bh * (int64_t)T * ld;
     float v[SM_MAXV];
     float mx = -INFINITY;
 #pragma unroll
@@ -467,7 +467,7 @@ __global__ __launch_bounds__(256) void relattn_softmax_fwd_kernel(float *__restr
         if (j < T) {
             const int flat = (i + 1) * T + j;
             const int r = flat / (T + 1), c = flat - r * (T + 1);
-            const float sh = c ? m[(int64_t)r * T + c - 1] : 0.f;
+            const float sh = c ? m[(int64_t)r * ld + c - 1] : 0.f;
             v[u] = keep[(int64_t)b * T + j] ? (a[j] + sh) * scale : -1e4f;
             mx = fmaxf(mx, v[u]);
         }
@@ -485,18 +485,19 @@ __global__ __launch_bounds__(256) void relattn_softmax_fwd_kernel(float *__restr
     for (int u = 0; u < SM_MAXV; ++u) {
         const int j = lane + u * 64;
         if (j < T) a[j] = v[u] * inv;
+        else if (j < ld) a[j] = 0.f;          // the padding columns of the row stay zero
     }
 }
 // ds = attn (dattn - sum_j attn dattn) * scale, zero at masked keys; in place over dattn (= d ac)
 __global__ __launch_bounds__(256) void relattn_softmax_bwd_kernel(const float *__restrict__ attn, float *__restrict__ dattn,
                                                                   const uint8_t *__restrict__ keep, float scale, int H,
-                                                                  int T, int64_t nrows) {
+                                                                  int T, int ld, int64_t nrows) {
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (row >= nrows) return;
     const int b = (int)(row / T / H);
-    const float *p = attn + row * T;
-    float *g = dattn + row * T;
+    const float *p = attn + row * ld;
+    float *g = dattn + row * ld;
     float pv[SM_MAXV], gv[SM_MAXV];
     float s = 0.f;
 #pragma unroll
@@ -511,41 +512,48 @@ __global__ __launch_bounds__(256) void relattn_softmax_bwd_kernel(const float *_
     for (int u = 0; u < SM_MAXV; ++u) {
         const int j = lane + u * 64;
         if (j < T) g[j] = keep[(int64_t)b * T + j] ? pv[u] * (gv[u] - s) * scale : 0.f;
+        else if (j < ld) g[j] = 0.f;
     }
 }
 // d bd[r, c'] = ds[i, j] with (i + 1, j) = divmod(r (T+1) + c' + 1, T), 0 for the first buffer row:
 // the inverse of the shift as a gather (every element of bd is read by at most one (i, j))
 __global__ __launch_bounds__(256) void relshift_bwd_kernel(const float *__restrict__ ds, float *__restrict__ dbd, int T,
-                                                           int64_t n) {
+                                                           int ld, int64_t n) {
     FOR_EACH(e, n) {
-        const int64_t bh = e / ((int64_t)T * T);
-        const int rc = (int)(e - bh * (int64_t)T * T);
-        const int r = rc / T, c = rc - r * T;
-        const int flat = r * (T + 1) + c + 1;
-        const int R = flat / T, j = flat - R * T;
-        dbd[e] = R >= 1 ? ds[bh * (int64_t)T * T + (int64_t)(R - 1) * T + j] : 0.f;
+        const int64_t bh = e / ((int64_t)T * ld);
+        const int rc = (int)(e - bh * (int64_t)T * ld);
+        const int r = rc / ld, c = rc - r * ld;
+        float v = 0.f;
+        if (c < T) {
+            const int flat = r * (T + 1) + c + 1;
+            const int R = flat / T, j = flat - R * T;
+            if (R >= 1) v = ds[bh * (int64_t)T * ld + (int64_t)(R - 1) * ld + j];
+        }
+        dbd[e] = v;
     }
 }
 
 extern "C" int asr_relattn_softmax_fwd(float *ac, const float *bd, const uint8_t *keep, float scale, int B, int H, int T,
-                                       void *stream) {
+                                       int ld, void *stream) {
     ASR_CHECK_ARG(ac && bd && keep, "relattn_softmax_fwd: null pointer");
+    ASR_CHECK_ARG(ld >= T && ld <= 64 * SM_MAXV, "relattn_softmax_fwd: bad row stride");
     ASR_CHECK_ARG(B > 0 && H > 0 && T > 0 && T <= 64 * SM_MAXV, "relattn_softmax_fwd: T must be in [1, %d]", 64 * SM_MAXV);
     const int64_t nrows = (int64_t)B * H * T;
     hipLaunchKernelGGL(relattn_softmax_fwd_kernel, dim3(cdiv(nrows, 4)), dim3(256), 0, (hipStream_t)stream, ac, bd, keep,
-                       scale, H, T, nrows);
+                       scale, H, T, ld, nrows);
     ASR_CHECK_LAUNCH("relattn_softmax_fwd_kernel");
     return ASR_OK;
 }
 extern "C" int asr_relattn_softmax_bwd(const float *attn, float *dattn, float *dbd, const uint8_t *keep, float scale,
-                                       int B, int H, int T, void *stream) {
+                                       int B, int H, int T, int ld, void *stream) {
     ASR_CHECK_ARG(attn && dattn && dbd && keep, "relattn_softmax_bwd: null pointer");
+    ASR_CHECK_ARG(ld >= T && ld <= 64 * SM_MAXV, "relattn_softmax_bwd: bad row stride");
     ASR_CHECK_ARG(B > 0 && H > 0 && T > 0 && T <= 64 * SM_MAXV, "relattn_softmax_bwd: T must be in [1, %d]", 64 * SM_MAXV);
     const int64_t nrows = (int64_t)B * H * T;
     hipLaunchKernelGGL(relattn_softmax_bwd_kernel, dim3(cdiv(nrows, 4)), dim3(256), 0, (hipStream_t)stream, attn, dattn,
-                       keep, scale, H, T, nrows);
-    hipLaunchKernelGGL(relshift_bwd_kernel, dim3(GRID1D(nrows * T)), dim3(256), 0, (hipStream_t)stream, dattn, dbd, T,
-                       nrows * T);
+                       keep, scale, H, T, ld, nrows);
+    hipLaunchKernelGGL(relshift_bwd_kernel, dim3(GRID1D(nrows * ld)), dim3(256), 0, (hipStream_t)stream, dattn, dbd, T,
+                       ld, nrows * ld);
     ASR_CHECK_LAUNCH("relattn_softmax_bwd_kernel");
     return ASR_OK;
 }

@@ -31,8 +31,18 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float *__restrict__ A
     const int m_begin = blockIdx.y * rows_per_block;
     const int m_end = min(M, m_begin + rows_per_block);
     float acc = 0.f;
-    if (n < N)
-        for (int m = m_begin + q; m < m_end; m += 4) acc += A[rowoff2(m, d, s0, s1) + n];
+    if (n < N) {
+        // eight independent loads in flight per thread (a serial chain of dependent adds would leave
+        // the pass latency-bound on tall matrices)
+        float a8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        int m = m_begin + q;
+        for (; m + 28 < m_end; m += 32) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) a8[u] += A[rowoff2(m + 4 * u, d, s0, s1) + n];
+        }
+        for (; m < m_end; m += 4) a8[0] += A[rowoff2(m, d, s0, s1) + n];
+        acc = ((a8[0] + a8[1]) + (a8[2] + a8[3])) + ((a8[4] + a8[5]) + (a8[6] + a8[7]));
+    }
     sh[q][threadIdx.x & 63] = acc;
     __syncthreads();
     if (q == 0 && n < N) {

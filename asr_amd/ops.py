@@ -31,7 +31,7 @@ def _req(t, dtype=torch.float32):
 def sgemm(A, B, Cm, M, N, K, *, a_mode=0, b_mode=0, a_stride=None, b_stride=None, c_stride=None,
           a_two=None, b_two=None, c_two=None, bias1=None, bias2=None, alpha=1.0, accumulate=False,
           act=0, splitk=1, nbatch=1, batch_a=0, batch_b=0, batch_c=0, a_off=0, b_off=0, c_off=0,
-          m_idx=None, k_idx=None, bias_two=None, keep=None, keep_scale=1.0, batch_two=None):
+          m_idx=None, k_idx=None, bias_two=None, keep=None, keep_scale=1.0, batch_two=None, pad_ok=0):
     """C[m,n] (+)= alpha * sum_k A(m,k) B(n,k) (+ biases); see include/asr_amd.h.
 
     *_stride: single row stride (elements); *_two = (d, s0, s1): two-level row
@@ -69,6 +69,7 @@ def sgemm(A, B, Cm, M, N, K, *, a_mode=0, b_mode=0, a_stride=None, b_stride=None
     d.c_keep_scale = keep_scale
     # batch_two = (batch_d, a1, b1, c1): two-level batch index, see include/asr_amd.h
     d.batch_d, d.batch_a1, d.batch_b1, d.batch_c1 = (0, 0, 0, 0) if batch_two is None else batch_two
+    d.pad_ok = pad_ok
     for name, idx, n in (("m_idx", m_idx, M), ("k_idx", k_idx, K)):
         if idx is None:
             setattr(d, name, 0)

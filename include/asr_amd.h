@@ -148,6 +148,10 @@ typedef struct {
      * interleaved inside the (B, T, heads * d_k) projections */
     int batch_d;
     int64_t batch_a1, batch_b1, batch_c1;
+    /* bit 0 (A) / bit 1 (B), mode 1 operands only: every row is readable up to the next multiple of
+     * 4 elements past M (resp. N) -- e.g. attention maps stored with a padded row stride -- so the
+     * 16-byte loads may be used although M (N) is not a multiple of 4 */
+    int pad_ok;
 } asr_gemm_desc;
 
 int asr_sgemm(const asr_gemm_desc *d, void *stream);
@@ -315,11 +319,13 @@ int asr_bn_swish_bwd(const float *dy, const float *x, const float *msum, const f
                      int C, float eps, void *stream);
 /* RelativeMultiHeadAttention (:99-102,110-137): ac (B,H,T,T) becomes
  * softmax_j(keep[b,j] ? (ac + rel_shift(bd)) * scale : -1e4) in place, T <= 1024.  Backward: dattn
- * becomes d ac (= the shifted score gradient) in place and dbd its un-shifted copy. */
+ * becomes d ac (= the shifted score gradient) in place and dbd its un-shifted copy.  All maps have
+ * row stride ld >= T (a multiple of 4 lets the products that read them use 16-byte loads,
+ * asr_gemm_desc.pad_ok); the kernels keep columns T..ld-1 at zero. */
 int asr_relattn_softmax_fwd(float *ac, const float *bd, const uint8_t *keep, float scale, int B, int H, int T,
-                            void *stream);
+                            int ld, void *stream);
 int asr_relattn_softmax_bwd(const float *attn, float *dattn, float *dbd, const uint8_t *keep, float scale,
-                            int B, int H, int T, void *stream);
+                            int B, int H, int T, int ld, void *stream);
 /* CNN_embedding (:386-407): patches of nn.Conv2d(Cin, Cout, 3, 2) on a channels-last map
  * x (B,Ti,Fi,Cin): col (B*To*Fo, 9*Cin) in (ki,kj,cin) order, To = (Ti-3)/2+1, Fo = (Fi-3)/2+1;
  * asr_col2im_3x3s2 is the data gradient (a gather, deterministic). */
