@@ -42,17 +42,40 @@ def _ln_fwd(x2, g, b):
     return y, mean, rstd
 
 
-def _ln_bwd(dy2, x2, g, mean, rstd, dx_acc):
-    """dx_acc += d LayerNorm / dx; returns (d gamma, d beta)."""
+def _ln_bwd(dy2, x2, g, mean, rstd, res):
+    """Returns (res + d LayerNorm / dx, d gamma, d beta); ``res`` = the gradient over the residual connection."""
     lib = _lib.load()
     rows, d = x2.shape
     nb = int(lib.asr_layernorm_bwd_blocks(rows))
     part = _e(nb, 2 * d, like=x2)
+    dx = torch.empty_like(x2)
     check(lib.asr_layernorm_bwd(dy2.data_ptr(), x2.data_ptr(), g.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
-                                dx_acc.data_ptr(), part.data_ptr(), rows, d, 1, _st()))
+                                dx.data_ptr(), part.data_ptr(), rows, d, res.data_ptr(), _st()))
     gb = _e(2 * d, like=x2)
     ops.colsum(part, gb)
-    return gb[:d], gb[d:]
+    return dx, gb[:d], gb[d:]
+
+
+def _residual_drop(x2, o, factor, p, training, ndrop):
+    """y = x + factor * drop^ndrop(o) in one pass; returns (y, mask or None, the factor of the gradient)."""
+    lib = _lib.load()
+    y = torch.empty_like(x2)
+    on = training and p > 0.0 and ndrop > 0
+    mask = torch.empty(x2.shape, device=x2.device, dtype=torch.uint8) if on else None
+    f = factor / (1.0 - p) ** ndrop if on else factor
+    check(lib.asr_residual_dropout(x2.data_ptr(), o.data_ptr(), y.data_ptr(), mask.data_ptr() if on else 0, x2.numel(),
+                                   C.c_float(f), C.c_float(p if on else 0.0), C.c_uint64(_seed(True, 1.0) if on else 0),
+                                   ndrop if on else 0, _st()))
+    return y, mask, f
+
+
+def _scale_mask(dy2, mask, f):
+    if mask is None and f == 1.0:
+        return dy2
+    out = torch.empty_like(dy2)
+    check(_lib.load().asr_scale_mask(dy2.data_ptr(), mask.data_ptr() if mask is not None else 0, out.data_ptr(),
+                                     dy2.numel(), C.c_float(f), _st()))
+    return out
 
 
 def _linear(x2, W2, b=None, act=0):
@@ -117,38 +140,32 @@ class _FFFunction(torch.autograd.Function):
     def forward(ctx, x, ln_w, ln_b, w1, b1, w2, b2, scale, p, training, n_out_drop):
         lib = _lib.load()
         x2 = _req(x).view(-1, x.shape[-1])
-        seed = _seed(training, p)
+        on = training and p > 0.0
         h, mean, rstd = _ln_fwd(x2, ln_w, ln_b)
         a = _linear(h, w1, b1)
         s = torch.empty_like(a)
-        check(lib.asr_swish_fwd(a.data_ptr(), s.data_ptr(), a.numel(), _st()))
-        s, m1 = _drop(s, p, training, seed)
+        m1 = torch.empty(a.shape, device=a.device, dtype=torch.uint8) if on else None
+        check(lib.asr_swish_fwd(a.data_ptr(), s.data_ptr(), m1.data_ptr() if on else 0, a.numel(),
+                                C.c_float(p if on else 0.0), C.c_uint64(_seed(training, p)), _st()))
         o = _linear(s, w2, b2)
-        masks = []
-        for i in range(n_out_drop):
-            o, m = _drop(o, p, training, seed + 1 + i)
-            masks.append(m)
-        y = _axpby(x2, o, 1.0, scale)
+        y, m_o, f = _residual_drop(x2, o, scale, p, training, n_out_drop)
         ctx.save_for_backward(x2, ln_w, w1, w2, mean, rstd, h, a, s)
-        ctx.aux = (scale, p, m1, masks)
+        ctx.aux = (p, m1, m_o, f)
         return y.view_as(x)
 
     @staticmethod
     def backward(ctx, dy):
         lib = _lib.load()
         x2, ln_w, w1, w2, mean, rstd, h, a, s = ctx.saved_tensors
-        scale, p, m1, masks = ctx.aux
+        p, m1, m_o, f = ctx.aux
         dy2 = dy.contiguous().view_as(x2)
-        do = _axpby(dy2, dy2, scale, 0.0) if scale != 1.0 else dy2
-        for m in reversed(masks):
-            do = _drop_bwd(do, m, p)
+        do = _scale_mask(dy2, m_o, f)
         ds, dW2, db2 = _linear_bwd(do, s, w2)
-        ds = _drop_bwd(ds, m1, p)
         da = torch.empty_like(a)
-        check(lib.asr_swish_bwd(ds.data_ptr(), a.data_ptr(), da.data_ptr(), a.numel(), _st()))
+        check(lib.asr_swish_bwd(ds.data_ptr(), a.data_ptr(), m1.data_ptr() if m1 is not None else 0, da.data_ptr(),
+                                a.numel(), C.c_float(p if m1 is not None else 0.0), _st()))
         dh, dW1, db1 = _linear_bwd(da, h, w1)
-        dx = dy2.clone()
-        dg, dbeta = _ln_bwd(dh, x2, ln_w, mean, rstd, dx)
+        dx, dg, dbeta = _ln_bwd(dh, x2, ln_w, mean, rstd, dy2)
         return dx.view_as(dy), dg, dbeta, dW1, db1, dW2, db2, None, None, None, None
 
 
@@ -193,22 +210,21 @@ class _RelAttnFunction(torch.autograd.Function):
         attn_d, m_att = _drop(attn, p, training, seed)
         cx = _e(B * T, d, like=x)
         _head_gemm(attn_d, vv, cx, T, dk, T, H, B, a=score, b=proj, c=proj, b_mode=1)   # attn v   :136
-        o, m_o = _drop(_linear(cx, wo, bo), p, training, seed + 1)
-        y = _axpby(x2, o, 1.0, 1.0)
+        y, m_o, f_o = _residual_drop(x2, _linear(cx, wo, bo), 1.0, p, training, 1)
         ctx.save_for_backward(x2, nw, wq, wk, wv, wpos, wo, pe, keep, mean, rstd, h, qu, qv, k, vv, pp, attn, attn_d, cx)
-        ctx.aux = (B, T, d, H, p, scale, m_att, m_o)
+        ctx.aux = (B, T, d, H, p, scale, m_att, m_o, f_o)
         return y.view_as(x)
 
     @staticmethod
     def backward(ctx, dy):
         lib = _lib.load()
         (x2, nw, wq, wk, wv, wpos, wo, pe, keep, mean, rstd, h, qu, qv, k, vv, pp, attn, attn_d, cx) = ctx.saved_tensors
-        B, T, d, H, p, scale, m_att, m_o = ctx.aux
+        B, T, d, H, p, scale, m_att, m_o, f_o = ctx.aux
         dk = d // H
         Tp = _pad4(T)
         proj, score, posp = (d, dk, T * d), (Tp, T * Tp, H * T * Tp), (d, dk, 0)
         dy2 = dy.contiguous().view_as(x2)
-        do = _drop_bwd(dy2, m_o, p)
+        do = _scale_mask(dy2, m_o, f_o)
         dcx, dWo, dbo = _linear_bwd(do, cx, wo)
         dattn = _e(B, H, T, Tp, like=x2)
         _head_gemm(dcx, vv, dattn, T, T, dk, H, B, a=proj, b=proj, c=score)                       # d attn = d ctx v^T
@@ -235,8 +251,7 @@ class _RelAttnFunction(torch.autograd.Function):
         _, dWv, dbv = _linear_bwd(dvv, h, wv, dx_out=dh, accumulate=True)
         dWpos = torch.empty_like(wpos)
         ops.matmul_tn(dpp, pe, dWpos)
-        dx = dy2.clone()
-        dg, dbeta = _ln_bwd(dh, x2, nw, mean, rstd, dx)
+        dx, dg, dbeta = _ln_bwd(dh, x2, nw, mean, rstd, dy2)
         return (dx.view_as(dy), dg, dbeta, dWq, dbq, dWk, dbk, dWv, dbv, dWpos, du.view(H, dk), dv.view(H, dk), dWo, dbo,
                 None, None, None, None, None)
 
@@ -275,21 +290,20 @@ class _ConvModuleFunction(torch.autograd.Function):
         s = torch.empty_like(c2)
         check(lib.asr_bn_swish_fwd(c2.data_ptr(), msum.data_ptr(), vsum.data_ptr(), C.c_float(ms), C.c_float(vs),
                                    bnw.data_ptr(), bnb.data_ptr(), s.data_ptr(), rows, d, LN_EPS, _st()))
-        o, m_o = _drop(_linear(s, W2, pw2b), p, training, _seed(training, p))
-        y = _axpby(x2, o, 1.0, 1.0)
+        y, m_o, f_o = _residual_drop(x2, _linear(s, W2, pw2b), 1.0, p, training, 1)
         ctx.save_for_backward(x2, lnw, pw1w, dww, cow, bnw, bnb, pw2w, mean, rstd, h, a, g, c1, c2, msum, vsum, s)
-        ctx.aux = (B, T, d, p, training, ms, vs, m_o)
+        ctx.aux = (B, T, d, p, training, ms, vs, m_o, f_o)
         return y.view_as(x)
 
     @staticmethod
     def backward(ctx, dy):
         lib = _lib.load()
         (x2, lnw, pw1w, dww, cow, bnw, bnb, pw2w, mean, rstd, h, a, g, c1, c2, msum, vsum, s) = ctx.saved_tensors
-        B, T, d, p, training, ms, vs, m_o = ctx.aux
+        B, T, d, p, training, ms, vs, m_o, f_o = ctx.aux
         rows = B * T
         W1, Wd, Wc, W2 = pw1w.view(2 * d, d), dww.view(d, KSIZE), cow.view(d, d), pw2w.view(d, d)
         dy2 = dy.contiguous().view_as(x2)
-        do = _drop_bwd(dy2, m_o, p)
+        do = _scale_mask(dy2, m_o, f_o)
         ds, dW2, db2 = _linear_bwd(do, s, W2)
         part = _e(int(lib.asr_bn_blocks(rows)), 2 * d, like=x2)
         check(lib.asr_bn_swish_bwd_part(ds.data_ptr(), c2.data_ptr(), msum.data_ptr(), vsum.data_ptr(), C.c_float(ms),
@@ -313,8 +327,7 @@ class _ConvModuleFunction(torch.autograd.Function):
         da = torch.empty_like(a)
         check(lib.asr_glu_bwd(dg.data_ptr(), a.data_ptr(), da.data_ptr(), rows, d, _st()))
         dh, dW1, db1 = _linear_bwd(da, h, W1)
-        dx = dy2.clone()
-        dgam, dbeta = _ln_bwd(dh, x2, lnw, mean, rstd, dx)
+        dx, dgam, dbeta = _ln_bwd(dh, x2, lnw, mean, rstd, dy2)
         return (dx.view_as(dy), dgam, dbeta, dW1.view_as(pw1w), db1, dWd.view_as(dww), ddb, dWc.view_as(cow), dbc,
                 sums[d:], sums[:d], dW2.view_as(pw2w), db2, None, None, None, None)
 
@@ -333,11 +346,14 @@ class _CnnEmbeddingFunction(torch.autograd.Function):
         src = _req(src)
         T1, F1 = (T - 3) // 2 + 1, (F - 3) // 2 + 1
         T2, F2 = (T1 - 3) // 2 + 1, (F1 - 3) // 2 + 1
-        col1 = _e(B * T1 * F1, 9, like=src)
-        check(lib.asr_im2col_3x3s2(src.data_ptr(), col1.data_ptr(), B, T, F, 1, _st()))
-        y1 = _linear(col1, w1.view(Cc, 9), b1, act=2)                       # (B,T1,F1,C)
+        # the 9 taps of the first convolution in rows of 12 (three zero columns): 16-byte rows for asr_sgemm
+        col1 = _e(B * T1 * F1, 12, like=src)
+        check(lib.asr_im2col_3x3s2(src.data_ptr(), col1.data_ptr(), B, T, F, 1, 12, _st()))
+        w1p = torch.zeros(Cc, 12, device=src.device, dtype=torch.float32)
+        w1p[:, :9].copy_(w1.view(Cc, 9))
+        y1 = _linear(col1, w1p, b1, act=2)                                  # (B,T1,F1,C)
         col2 = _e(B * T2 * F2, 9 * Cc, like=src)
-        check(lib.asr_im2col_3x3s2(y1.data_ptr(), col2.data_ptr(), B, T1, F1, Cc, _st()))
+        check(lib.asr_im2col_3x3s2(y1.data_ptr(), col2.data_ptr(), B, T1, F1, Cc, 9 * Cc, _st()))
         w2p = ops.transpose(w2.view(Cc, Cc, 9)).view(Cc, 9 * Cc)            # (Cout, ki, kj, Cin)
         y2 = _linear(col2, w2p, b2, act=2)                                  # (B,T2,F2,C)
         woutp = ops.transpose(wout.view(-1, Cc, F2)).view(-1, F2 * Cc)      # (odim, F2, C)
@@ -358,15 +374,13 @@ class _CnnEmbeddingFunction(torch.autograd.Function):
         check(lib.asr_relu_bwd(dy2.data_ptr(), y2.data_ptr(), dpre2.data_ptr(), y2.numel(), _st()))
         dcol2, dw2p, db2 = _linear_bwd(dpre2, col2, w2p)
         dw2 = ops.transpose(dw2p.view(Cc, 9, Cc)).view(Cc, Cc, 3, 3)
-        dy1 = torch.empty_like(y1)
-        check(lib.asr_col2im_3x3s2(dcol2.data_ptr(), dy1.data_ptr(), B, T1, F1, Cc, _st()))
-        dpre1 = torch.empty_like(y1)
-        check(lib.asr_relu_bwd(dy1.data_ptr(), y1.data_ptr(), dpre1.data_ptr(), y1.numel(), _st()))
-        dw1 = _e(Cc, 9, like=y1)
-        ops.matmul_tn(dpre1, col1, dw1)
+        dpre1 = torch.empty_like(y1)                                        # col2im and the ReLU gradient in one pass
+        check(lib.asr_col2im_3x3s2(dcol2.data_ptr(), y1.data_ptr(), dpre1.data_ptr(), B, T1, F1, Cc, _st()))
+        dw1p = _e(Cc, 12, like=y1)
+        ops.matmul_tn(dpre1.view(-1, Cc), col1, dw1p)
         db1 = _e(Cc, like=y1)
-        ops.colsum(dpre1, db1)
-        return None, dw1.view(Cc, 1, 3, 3), db1, dw2, db2, dwout
+        ops.colsum(dpre1.view(-1, Cc), db1)
+        return None, dw1p[:, :9].reshape(Cc, 1, 3, 3), db1, dw2, db2, dwout
 
 
 # ------------------------------------------------------------------- module tree --

@@ -111,9 +111,11 @@ SYMBOLS = {
     # Conformer encoder (csrc/conformer.hip)
     "asr_layernorm_fwd": (C.c_int, [c_f] * 6 + [c_i64, C.c_int, C.c_float, c_f]),
     "asr_layernorm_bwd_blocks": (c_i64, [c_i64]),
-    "asr_layernorm_bwd": (C.c_int, [c_f] * 7 + [c_i64, C.c_int, C.c_int, c_f]),
-    "asr_swish_fwd": (C.c_int, [c_f, c_f, c_i64, c_f]),
-    "asr_swish_bwd": (C.c_int, [c_f, c_f, c_f, c_i64, c_f]),
+    "asr_layernorm_bwd": (C.c_int, [c_f] * 7 + [c_i64, C.c_int, c_f, c_f]),
+    "asr_swish_fwd": (C.c_int, [c_f, c_f, c_f, c_i64, C.c_float, C.c_uint64, c_f]),
+    "asr_swish_bwd": (C.c_int, [c_f, c_f, c_f, c_f, c_i64, C.c_float, c_f]),
+    "asr_residual_dropout": (C.c_int, [c_f, c_f, c_f, c_f, c_i64, C.c_float, C.c_float, C.c_uint64, C.c_int, c_f]),
+    "asr_scale_mask": (C.c_int, [c_f, c_f, c_f, c_i64, C.c_float, c_f]),
     "asr_glu_fwd": (C.c_int, [c_f, c_f, c_i64, C.c_int, c_f]),
     "asr_glu_bwd": (C.c_int, [c_f, c_f, c_f, c_i64, C.c_int, c_f]),
     "asr_relu_bwd": (C.c_int, [c_f, c_f, c_f, c_i64, c_f]),
@@ -131,8 +133,8 @@ SYMBOLS = {
                                    C.c_float, c_f]),
     "asr_relattn_softmax_fwd": (C.c_int, [c_f, c_f, c_f, C.c_float, C.c_int, C.c_int, C.c_int, C.c_int, c_f]),
     "asr_relattn_softmax_bwd": (C.c_int, [c_f, c_f, c_f, c_f, C.c_float, C.c_int, C.c_int, C.c_int, C.c_int, c_f]),
-    "asr_im2col_3x3s2": (C.c_int, [c_f, c_f, C.c_int, C.c_int, C.c_int, C.c_int, c_f]),
-    "asr_col2im_3x3s2": (C.c_int, [c_f, c_f, C.c_int, C.c_int, C.c_int, C.c_int, c_f]),
+    "asr_im2col_3x3s2": (C.c_int, [c_f, c_f, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_f]),
+    "asr_col2im_3x3s2": (C.c_int, [c_f, c_f, c_f, C.c_int, C.c_int, C.c_int, C.c_int, c_f]),
 }
 
 _lib = None

@@ -118,6 +118,18 @@ __device__ __forceinline__ float sigmoid_f(float x) {
 // sigmoid in the tanh form of Models/decoder.py:269-279
 __device__ __forceinline__ float sigmoid_tanh_form(float x) { return 0.5f * tanh_f(0.5f * x) + 0.5f; }
 
+// the counter-based hash behind every dropout mask: element i is kept iff
+// asr_mix32(seed + i * golden) >= p * 2^32 (asr_dropout_fwd, misc.hip)
+__device__ __forceinline__ uint32_t asr_mix32(uint64_t x) {
+    x ^= x >> 33; x *= 0xff51afd7ed558ccdULL;
+    x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ULL;
+    x ^= x >> 33;
+    return (uint32_t)x;
+}
+__device__ __forceinline__ bool asr_keep(uint64_t seed, int64_t i, uint32_t thresh) {
+    return asr_mix32(seed + (uint64_t)i * 0x9E3779B97F4A7C15ULL) >= thresh;
+}
+
 __host__ __device__ __forceinline__ int64_t rowoff2(int64_t i, int d, int64_t s0, int64_t s1) {
     return (i / d) * s1 + (i % d) * s0;
 }

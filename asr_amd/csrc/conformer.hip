@@ -57,7 +57,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float *__restrict__ x
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const float *__restrict__ dy, const float *__restrict__ x,
                                                      const float *__restrict__ g, const float *__restrict__ mean,
                                                      const float *__restrict__ rstd, float *__restrict__ dx,
-                                                     float *__restrict__ part, int64_t rows, int d, int accumulate) {
+                                                     float *__restrict__ part, int64_t rows, int d, const float *__restrict__ res) {
     __shared__ float red[4][2][64 * LN_MAXV / 4];   // used in d-sized slices, see below
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int64_t r0 = (int64_t)blockIdx.x * LN_BWD_ROWS;
@@ -91,7 +91,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float *__restrict__ d
             const int c = lane + i * 64;
             if (c < d) {
                 float v = rs * (gy[i] - s1 - xh[i] * s2);
-                if (accumulate) v += dx[r * d + c];
+                if (res) v += res[r * d + c];
                 dx[r * d + c] = v;
             }
         }
@@ -127,12 +127,12 @@ extern "C" int asr_layernorm_fwd(const float *x, const float *gamma, const float
 }
 extern "C" int64_t asr_layernorm_bwd_blocks(int64_t rows) { return rows > 0 ? (rows + LN_BWD_ROWS - 1) / LN_BWD_ROWS : 1; }
 extern "C" int asr_layernorm_bwd(const float *dy, const float *x, const float *gamma, const float *mean,
-                                 const float *rstd, float *dx, float *part, int64_t rows, int d, int accumulate,
+                                 const float *rstd, float *dx, float *part, int64_t rows, int d, const float *res,
                                  void *stream) {
     ASR_CHECK_ARG(dy && x && gamma && mean && rstd && dx && part, "layernorm_bwd: null pointer");
     ASR_CHECK_ARG(rows > 0 && d > 0 && d <= 64 * LN_MAXV, "layernorm_bwd: bad shape");
     hipLaunchKernelGGL(ln_bwd_kernel, dim3((unsigned)asr_layernorm_bwd_blocks(rows)), dim3(256), 0, (hipStream_t)stream,
-                       dy, x, gamma, mean, rstd, dx, part, rows, d, accumulate);
+                       dy, x, gamma, mean, rstd, dx, part, rows, d, res);
     ASR_CHECK_LAUNCH("ln_bwd_kernel");
     return ASR_OK;
 }
@@ -141,15 +141,50 @@ extern "C" int asr_layernorm_bwd(const float *dy, const float *x, const float *g
 // swish (:175-177) x sigmoid(x); GLU (:232-233) out * sigmoid(gate) over the two halves of a row;
 // ReLU gradient for the subsampling convolutions (:391-394); out = a x + b y for residuals
 // (:259,263-265) and running statistics.
-__global__ __launch_bounds__(256) void swish_fwd_kernel(const float *__restrict__ x, float *__restrict__ y, int64_t n) {
-    FOR_EACH(i, n) { const float v = x[i]; y[i] = v * sigmoid_exact(v); }
+// mask != NULL: the inverted dropout that follows the activation (:205) in the same pass
+__global__ __launch_bounds__(256) void swish_fwd_kernel(const float *__restrict__ x, float *__restrict__ y,
+                                                        uint8_t *__restrict__ mask, int64_t n, uint32_t thresh,
+                                                        float scale, uint64_t seed) {
+    FOR_EACH(i, n) {
+        const float v = x[i];
+        float s = v * sigmoid_exact(v);
+        if (mask) {
+            const bool keep = asr_keep(seed, i, thresh);
+            mask[i] = keep;
+            s = keep ? s * scale : 0.f;
+        }
+        y[i] = s;
+    }
 }
 __global__ __launch_bounds__(256) void swish_bwd_kernel(const float *__restrict__ dy, const float *__restrict__ x,
-                                                        float *__restrict__ dx, int64_t n) {
+                                                        const uint8_t *__restrict__ mask, float *__restrict__ dx,
+                                                        int64_t n, float scale) {
     FOR_EACH(i, n) {
         const float v = x[i], s = sigmoid_exact(v);
-        dx[i] = dy[i] * s * (1.f + v * (1.f - s));
+        float g = dy[i];
+        if (mask) g = mask[i] ? g * scale : 0.f;
+        dx[i] = g * s * (1.f + v * (1.f - s));
     }
+}
+// y = x + factor * keep * o with keep = the AND of ndrop dropout draws (seeds seed, seed + 1, ...): the output
+// dropouts of a block and its residual connection (:207,259,263-265) in one pass; mask == NULL: y = x + factor * o
+__global__ __launch_bounds__(256) void residual_dropout_kernel(const float *__restrict__ x, const float *__restrict__ o,
+                                                               float *__restrict__ y, uint8_t *__restrict__ mask, int64_t n,
+                                                               float factor, uint32_t thresh, uint64_t seed, int ndrop) {
+    FOR_EACH(i, n) {
+        float v = o[i] * factor;
+        if (mask) {
+            bool keep = true;
+            for (int k = 0; k < ndrop; ++k) keep = keep && asr_keep(seed + k, i, thresh);
+            mask[i] = keep;
+            v = keep ? v : 0.f;
+        }
+        y[i] = x[i] + v;
+    }
+}
+__global__ __launch_bounds__(256) void scale_mask_kernel(const float *__restrict__ dy, const uint8_t *__restrict__ mask,
+                                                         float *__restrict__ out, int64_t n, float factor) {
+    FOR_EACH(i, n) out[i] = (!mask || mask[i]) ? dy[i] * factor : 0.f;
 }
 __global__ __launch_bounds__(256) void glu_fwd_kernel(const float *__restrict__ x, float *__restrict__ y, int64_t rows, int d) {
     FOR_EACH(i, rows * d) {
@@ -196,12 +231,25 @@ __global__ __launch_bounds__(256) void add_two_bias_kernel(const float *__restri
         ASR_CHECK_LAUNCH(name);                                                         \
         return ASR_OK;                                                                  \
     }
-extern "C" int asr_swish_fwd(const float *x, float *y, int64_t n, void *stream)
-    EW_ENTRY("swish_fwd", x && y && n >= 0,
-             hipLaunchKernelGGL(swish_fwd_kernel, dim3(GRID1D(n)), dim3(256), 0, (hipStream_t)stream, x, y, n))
-extern "C" int asr_swish_bwd(const float *dy, const float *x, float *dx, int64_t n, void *stream)
-    EW_ENTRY("swish_bwd", dy && x && dx && n >= 0,
-             hipLaunchKernelGGL(swish_bwd_kernel, dim3(GRID1D(n)), dim3(256), 0, (hipStream_t)stream, dy, x, dx, n))
+static uint32_t drop_thresh(float p) { return (uint32_t)((double)p * 4294967296.0); }
+extern "C" int asr_swish_fwd(const float *x, float *y, uint8_t *mask, int64_t n, float p, uint64_t seed, void *stream)
+    EW_ENTRY("swish_fwd", x && y && n >= 0 && p >= 0.f && p < 1.f,
+             hipLaunchKernelGGL(swish_fwd_kernel, dim3(GRID1D(n)), dim3(256), 0, (hipStream_t)stream, x, y, mask, n,
+                                drop_thresh(p), 1.0f / (1.0f - p), seed))
+extern "C" int asr_swish_bwd(const float *dy, const float *x, const uint8_t *mask, float *dx, int64_t n, float p,
+                             void *stream)
+    EW_ENTRY("swish_bwd", dy && x && dx && n >= 0 && p >= 0.f && p < 1.f,
+             hipLaunchKernelGGL(swish_bwd_kernel, dim3(GRID1D(n)), dim3(256), 0, (hipStream_t)stream, dy, x, mask, dx, n,
+                                1.0f / (1.0f - p)))
+extern "C" int asr_residual_dropout(const float *x, const float *o, float *y, uint8_t *mask, int64_t n, float factor,
+                                    float p, uint64_t seed, int ndrop, void *stream)
+    EW_ENTRY("residual_dropout", x && o && y && n >= 0 && p >= 0.f && p < 1.f && ndrop >= 0 && ndrop <= 4,
+             hipLaunchKernelGGL(residual_dropout_kernel, dim3(GRID1D(n)), dim3(256), 0, (hipStream_t)stream, x, o, y, mask,
+                                n, factor, drop_thresh(p), seed, ndrop))
+extern "C" int asr_scale_mask(const float *dy, const uint8_t *mask, float *out, int64_t n, float factor, void *stream)
+    EW_ENTRY("scale_mask", dy && out && n >= 0,
+             hipLaunchKernelGGL(scale_mask_kernel, dim3(GRID1D(n)), dim3(256), 0, (hipStream_t)stream, dy, mask, out, n,
+                                factor))
 extern "C" int asr_relu_bwd(const float *dy, const float *y, float *dx, int64_t n, void *stream)
     EW_ENTRY("relu_bwd", dy && y && dx && n >= 0,
              hipLaunchKernelGGL(relu_bwd_kernel, dim3(GRID1D(n)), dim3(256), 0, (hipStream_t)stream, dy, y, dx, n))
@@ -563,8 +611,11 @@ extern "C" int asr_relattn_softmax_bwd(const float *attn, float *dattn, float *d
 // (b, to, fo) of col holds its 9 Cin inputs in (ki, kj, cin) order, To = (Ti-3)/2+1, Fo = (Fi-3)/2+1; the
 // convolution itself is col @ W'^T on asr_sgemm with W' = the weight permuted to (Cout, 3, 3, Cin).
 __global__ __launch_bounds__(256) void im2col_3x3s2_kernel(const float *__restrict__ x, float *__restrict__ col, int Ti,
-                                                           int Fi, int Cin, int To, int Fo, int64_t n) {
-    FOR_EACH(e, n) {
+                                                           int Fi, int Cin, int To, int Fo, int ld, int64_t n) {
+    FOR_EACH(e0, n) {
+        const int kk = (int)(e0 % ld);
+        if (kk >= 9 * Cin) { col[e0] = 0.f; continue; }      // zero columns up to the padded row length
+        const int64_t e = (e0 / ld) * 9 * Cin + kk;
         const int cin = (int)(e % Cin);
         int64_t q = e / Cin;
         const int kj = (int)(q % 3); q /= 3;
@@ -572,12 +623,13 @@ __global__ __launch_bounds__(256) void im2col_3x3s2_kernel(const float *__restri
         const int fo = (int)(q % Fo); q /= Fo;
         const int to = (int)(q % To);
         const int64_t b = q / To;
-        col[e] = x[((b * Ti + 2 * to + ki) * Fi + 2 * fo + kj) * Cin + cin];
+        col[e0] = x[((b * Ti + 2 * to + ki) * Fi + 2 * fo + kj) * Cin + cin];
     }
 }
 // the data gradient as a gather: dx[b,ti,fi,c] = sum over the (ki, kj) whose output position exists
-__global__ __launch_bounds__(256) void col2im_3x3s2_kernel(const float *__restrict__ dcol, float *__restrict__ dx, int Ti,
-                                                           int Fi, int Cin, int To, int Fo, int64_t n) {
+__global__ __launch_bounds__(256) void col2im_3x3s2_kernel(const float *__restrict__ dcol, const float *__restrict__ y,
+                                                           float *__restrict__ dx, int Ti, int Fi, int Cin, int To, int Fo,
+                                                           int64_t n) {
     FOR_EACH(e, n) {
         const int c = (int)(e % Cin);
         int64_t q = e / Cin;
@@ -585,6 +637,7 @@ __global__ __launch_bounds__(256) void col2im_3x3s2_kernel(const float *__restri
         const int ti = (int)(q % Ti);
         const int64_t b = q / Ti;
         float acc = 0.f;
+        if (y && !(y[e] > 0.f)) { dx[e] = 0.f; continue; }   // gradient of the ReLU that produced this map
 #pragma unroll
         for (int ki = 0; ki < 3; ++ki) {
             const int t2 = ti - ki;
@@ -599,21 +652,22 @@ __global__ __launch_bounds__(256) void col2im_3x3s2_kernel(const float *__restri
         dx[e] = acc;
     }
 }
-extern "C" int asr_im2col_3x3s2(const float *x, float *col, int B, int Ti, int Fi, int Cin, void *stream) {
-    ASR_CHECK_ARG(x && col && B > 0 && Ti >= 3 && Fi >= 3 && Cin > 0, "im2col_3x3s2: bad argument");
+extern "C" int asr_im2col_3x3s2(const float *x, float *col, int B, int Ti, int Fi, int Cin, int ld, void *stream) {
+    ASR_CHECK_ARG(x && col && B > 0 && Ti >= 3 && Fi >= 3 && Cin > 0 && ld >= 9 * Cin, "im2col_3x3s2: bad argument");
     const int To = (Ti - 3) / 2 + 1, Fo = (Fi - 3) / 2 + 1;
-    const int64_t n = (int64_t)B * To * Fo * 9 * Cin;
+    const int64_t n = (int64_t)B * To * Fo * ld;
     hipLaunchKernelGGL(im2col_3x3s2_kernel, dim3(GRID1D(n)), dim3(256), 0, (hipStream_t)stream, x, col, Ti, Fi, Cin, To,
-                       Fo, n);
+                       Fo, ld, n);
     ASR_CHECK_LAUNCH("im2col_3x3s2_kernel");
     return ASR_OK;
 }
-extern "C" int asr_col2im_3x3s2(const float *dcol, float *dx, int B, int Ti, int Fi, int Cin, void *stream) {
+extern "C" int asr_col2im_3x3s2(const float *dcol, const float *y, float *dx, int B, int Ti, int Fi, int Cin,
+                                void *stream) {
     ASR_CHECK_ARG(dcol && dx && B > 0 && Ti >= 3 && Fi >= 3 && Cin > 0, "col2im_3x3s2: bad argument");
     const int To = (Ti - 3) / 2 + 1, Fo = (Fi - 3) / 2 + 1;
     const int64_t n = (int64_t)B * Ti * Fi * Cin;
-    hipLaunchKernelGGL(col2im_3x3s2_kernel, dim3(GRID1D(n)), dim3(256), 0, (hipStream_t)stream, dcol, dx, Ti, Fi, Cin, To,
-                       Fo, n);
+    hipLaunchKernelGGL(col2im_3x3s2_kernel, dim3(GRID1D(n)), dim3(256), 0, (hipStream_t)stream, dcol, y, dx, Ti, Fi, Cin,
+                       To, Fo, n);
     ASR_CHECK_LAUNCH("col2im_3x3s2_kernel");
     return ASR_OK;
 }

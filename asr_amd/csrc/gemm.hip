@@ -361,15 +361,22 @@ extern "C" int asr_sgemm(const asr_gemm_desc *din, void *stream) {
         const char *e = getenv("ASR_GEMM_TILE");
         tile_cfg = e ? atoi(e) : 2;   // 128 x 64 measured best on the config-2 shapes (tools/gemm_bench.py)
     }
-    if (big && fast && tile_cfg == 1) {          // experiment: 64 x 128 tiles
+    // few tiles (e.g. N = 256: the Conformer's d_model) leave 128 x 64 workgroups unevenly spread over
+    // the 256 CUs; 64 x 64 tiles double the count (65 -> 78 TFLOP/s at 11968 x 256 x 2048,
+    // tools/conformer_gemms.py).  Split-K launches keep their tuned shape.
+    int cfg = tile_cfg;
+    if (cfg == 2 && big && fast && splitk == 1 &&
+        (int64_t)cdiv(d.M, 128) * cdiv(d.N, 64) * d.nbatch < 1024)
+        cfg = 3;
+    if (big && fast && cfg == 1) {          // experiment: 64 x 128 tiles
         dim3 grid(cdiv(d.N, 128), cdiv(d.M, 64), d.nbatch * splitk);
         ASR_CHECK_ARG(grid.y <= 65535 && grid.z <= 65535, "sgemm: grid too large");
         LAUNCH_MODES(64, 128, 16, true)
-    } else if (big && fast && tile_cfg == 2) {   // default: 128 x 64 tiles (more, smaller tiles: shorter tail)
+    } else if (big && fast && cfg == 2) {   // default: 128 x 64 tiles (more, smaller tiles: shorter tail)
         dim3 grid(cdiv(d.N, 64), cdiv(d.M, 128), d.nbatch * splitk);
         ASR_CHECK_ARG(grid.y <= 65535 && grid.z <= 65535, "sgemm: grid too large");
         if (GK == 32) { LAUNCH_MODES(128, 64, 32, true) } else { LAUNCH_MODES(128, 64, 16, true) }
-    } else if (big && fast && tile_cfg == 3) {   // experiment: 64 x 64 tiles (short workgroups)
+    } else if (big && fast && cfg == 3) {   // experiment: 64 x 64 tiles (short workgroups)
         dim3 grid(cdiv(d.N, 64), cdiv(d.M, 64), d.nbatch * splitk);
         ASR_CHECK_ARG(grid.y <= 65535 && grid.z <= 65535, "sgemm: grid too large");
         if (GK == 32) { LAUNCH_MODES(64, 64, 32, true) } else { LAUNCH_MODES(64, 64, 16, true) }

@@ -279,16 +279,26 @@ int asr_dropout_fwd_block(const float *x, float *y, uint8_t *mask, int64_t rows,
 /* nn.LayerNorm(d) (:161,194,218,250), d <= 1024: y, and per row mean / rstd for the backward */
 int asr_layernorm_fwd(const float *x, const float *gamma, const float *beta, float *y, float *mean,
                       float *rstd, int64_t rows, int d, float eps, void *stream);
-/* dx (+)= its gradient; part[asr_layernorm_bwd_blocks(rows)][2][d] = per-block sums of dy*xhat
- * (d gamma) and dy (d beta), to be summed with asr_colsum (deterministic) */
+/* dx = its gradient (+ res when res != NULL: the gradient arriving over the residual connection);
+ * part[asr_layernorm_bwd_blocks(rows)][2][d] = per-block sums of dy*xhat (d gamma) and dy (d beta),
+ * to be summed with asr_colsum (deterministic) */
 int64_t asr_layernorm_bwd_blocks(int64_t rows);
 int asr_layernorm_bwd(const float *dy, const float *x, const float *gamma, const float *mean,
-                      const float *rstd, float *dx, float *part, int64_t rows, int d, int accumulate,
+                      const float *rstd, float *dx, float *part, int64_t rows, int d, const float *res,
                       void *stream);
 /* Swish (:175-177), GLU over the halves of a (rows, 2d) tensor (:232-233), ReLU gradient (:391-394),
  * out = a*x + b*y (residuals :259,263-265; running statistics), qu = q + u / qv = q + v (:94-95) */
-int asr_swish_fwd(const float *x, float *y, int64_t n, void *stream);
-int asr_swish_bwd(const float *dy, const float *x, float *dx, int64_t n, void *stream);
+/* (mask != NULL: followed by the inverted dropout of :205 in the same pass, mask as in asr_dropout_fwd) */
+int asr_swish_fwd(const float *x, float *y, uint8_t *mask, int64_t n, float p, uint64_t seed, void *stream);
+int asr_swish_bwd(const float *dy, const float *x, const uint8_t *mask, float *dx, int64_t n, float p,
+                  void *stream);
+/* y = x + factor * keep * o, keep = AND of ndrop dropout draws (seeds seed, seed+1, ...), written to mask:
+ * a block's output dropouts (:207 and :263-265) and residual sum in one pass (factor carries the
+ * 1/(1-p)^ndrop and the 0.5 of :259); mask == NULL: no dropout.  asr_scale_mask is its gradient
+ * w.r.t. o: out = mask ? dy * factor : 0. */
+int asr_residual_dropout(const float *x, const float *o, float *y, uint8_t *mask, int64_t n, float factor,
+                         float p, uint64_t seed, int ndrop, void *stream);
+int asr_scale_mask(const float *dy, const uint8_t *mask, float *out, int64_t n, float factor, void *stream);
 int asr_glu_fwd(const float *x, float *y, int64_t rows, int d, void *stream);
 int asr_glu_bwd(const float *dy, const float *x, float *dx, int64_t rows, int d, void *stream);
 int asr_relu_bwd(const float *dy, const float *y, float *dx, int64_t n, void *stream);
@@ -327,10 +337,13 @@ int asr_relattn_softmax_fwd(float *ac, const float *bd, const uint8_t *keep, flo
 int asr_relattn_softmax_bwd(const float *attn, float *dattn, float *dbd, const uint8_t *keep, float scale,
                             int B, int H, int T, int ld, void *stream);
 /* CNN_embedding (:386-407): patches of nn.Conv2d(Cin, Cout, 3, 2) on a channels-last map
- * x (B,Ti,Fi,Cin): col (B*To*Fo, 9*Cin) in (ki,kj,cin) order, To = (Ti-3)/2+1, Fo = (Fi-3)/2+1;
- * asr_col2im_3x3s2 is the data gradient (a gather, deterministic). */
-int asr_im2col_3x3s2(const float *x, float *col, int B, int Ti, int Fi, int Cin, void *stream);
-int asr_col2im_3x3s2(const float *dcol, float *dx, int B, int Ti, int Fi, int Cin, void *stream);
+ * x (B,Ti,Fi,Cin): col (B*To*Fo, ld) in (ki,kj,cin) order, To = (Ti-3)/2+1, Fo = (Fi-3)/2+1, columns
+ * 9*Cin..ld-1 zero (ld = 12 gives the first convolution, Cin = 1, 16-byte rows);
+ * asr_col2im_3x3s2 is the data gradient (a gather over rows of length 9*Cin, deterministic), times
+ * the gradient of the ReLU that produced the map y when y != NULL. */
+int asr_im2col_3x3s2(const float *x, float *col, int B, int Ti, int Fi, int Cin, int ld, void *stream);
+int asr_col2im_3x3s2(const float *dcol, const float *y, float *dx, int B, int Ti, int Fi, int Cin,
+                     void *stream);
 
 /* ------------------------------------------------- attention decoder loop --
  * Replaces the L-step teacher-forced loop Models/decoder.py:52-60 with
