@@ -239,9 +239,11 @@ class _RelAttnFunction(torch.autograd.Function):
         _head_gemm(dattn, qu, dkk, T, dk, T, H, B, a=score, b=proj, c=proj, a_mode=1, b_mode=1, pad_ok=1)    # d ac^T (q + u)
         _head_gemm(dbd, pp, dqv, T, dk, T, H, B, a=score, b=posp, c=proj, b_mode=1)                # d bd p
         # d p[h] = sum_b d bd[b,h]^T (q + v)[b,:,h,:]: the reduction runs over (b, i) through a two-level row map
-        dpp = torch.empty_like(pp)
+        # (only heads x ceil(T/64) tiles: split the long reduction over workgroups, 464 -> 52 us at config 5)
+        sk = max(1, min(16, (B * T) // 512))
+        dpp = torch.zeros_like(pp) if sk > 1 else torch.empty_like(pp)
         ops.sgemm(dbd, qv, dpp, T, dk, B * T, a_mode=1, b_mode=1, a_two=(T, Tp, H * T * Tp), b_stride=d, c_stride=d,
-                  nbatch=H, batch_a=T * Tp, batch_b=dk, batch_c=dk, pad_ok=1)
+                  nbatch=H, batch_a=T * Tp, batch_b=dk, batch_c=dk, pad_ok=1, splitk=sk)
         du, dv = _e(d, like=x2), _e(d, like=x2)
         ops.colsum(dqu, du)
         ops.colsum(dqv, dv)

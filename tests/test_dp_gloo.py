@@ -16,7 +16,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, out):
+def _worker(rank, world, port, out, conformer=False):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -24,8 +24,15 @@ def _worker(rank, world, port, out):
     from asr_amd.parallel import BucketedGradReducer
     from oracle import ref_model as R
     hp = R.make_hp(num_hidden_nodes=8, num_encoder_layer=2, lmfb_dim=4, num_classes=7, frame_stacking=1)
+    if conformer:
+        hp = R.make_hp(num_hidden_nodes_encoder=256, num_hidden_nodes_decoder=8, lmfb_dim=20, num_classes=7,
+                       frame_stacking=1, encoder_type="Conformer")
     torch.manual_seed(100 + rank)                  # different weights per rank on purpose
     m = AttModel(hp)
+    if conformer:
+        import asr_amd.parallel as par
+        m.encoder.encoder.layers = torch.nn.Sequential(*list(m.encoder.encoder.layers)[:6])   # 6 layers: buckets of 4 + 2
+        assert par.CONFORMER_LAYERS_PER_BUCKET == 4
     red = BucketedGradReducer(m)
     red.broadcast_parameters()
     w0 = torch.cat([p.detach().reshape(-1) for p in m.parameters()])
@@ -44,7 +51,15 @@ def _worker(rank, world, port, out):
     # bucket order: decoder first, then encoder layers top-down
     names = {p: n for n, p in m.named_parameters()}
     order = [names[ps[0]] for ps in red.buckets]
-    ok = ok and order[0].startswith("decoder.") and order[1].endswith("_l1") and order[2].endswith("_l0")
+    if conformer:
+        ok = ok and len(order) == 4 and order[0].startswith("decoder.") and order[1].startswith("encoder.encoder.layers.5.") \
+            and order[2].startswith("encoder.encoder.layers.1.") and order[3].startswith("encoder.cnn_encoder.")
+        bs = [torch.cat([b.detach().reshape(-1).float() for b in m.buffers()])]
+        allb = [torch.zeros_like(bs[0]) for _ in range(world)]
+        dist.all_gather(allb, bs[0])
+        ok = ok and all(torch.equal(allb[0], b) for b in allb)
+    else:
+        ok = ok and order[0].startswith("decoder.") and order[1].endswith("_l1") and order[2].endswith("_l0")
     ok = ok and red.bytes_per_step() == 4 * sum(p.numel() for p in m.parameters())
     out[rank] = ok
     dist.destroy_process_group()
@@ -56,4 +71,15 @@ def test_reducer_world2_gloo():
     mgr = mp.Manager()
     out = mgr.dict()
     mp.spawn(_worker, args=(world, port, out), nprocs=world, join=True)
+    assert all(out.get(r) for r in range(world)), dict(out)
+
+
+def test_reducer_world2_gloo_conformer():
+    """The same reducer on AttModel(encoder_type='Conformer'): decoder, then Conformer layers top-down four to a
+    bucket, then the subsampling; buffers (BatchNorm statistics) broadcast with the parameters."""
+    world = 2
+    port = _free_port()
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker, args=(world, port, out, True), nprocs=world, join=True)
     assert all(out.get(r) for r in range(world)), dict(out)
