@@ -20,7 +20,15 @@ extern "C" const char *asr_last_error(void) { return g_err; }
 // out[n] (+)= sum_m A[rowoff(m) + n].  Two stages so the result is
 // deterministic: each block sums a strip of rows into part[strip][n] (or
 // straight into out when one strip suffices).
-#define CS_ROWS 512
+// Strip height: enough strips for about 1024 workgroups (a 12 MB matrix of 256 columns would otherwise
+// be summed by 96 workgroups), at least 32 rows each.
+static int colsum_strips(int M, int N) {
+    const int colblocks = cdiv(N, 64);
+    int strips = cdiv(1024, colblocks);
+    const int max_strips = cdiv(M > 0 ? M : 1, 32);
+    if (strips > max_strips) strips = max_strips;
+    return strips < 1 ? 1 : strips;
+}
 __global__ __launch_bounds__(256) void colsum_kernel(const float *__restrict__ A, int M, int N,
                                                      int64_t s0, int64_t s1, int d,
                                                      float *__restrict__ out, int accumulate,
@@ -59,21 +67,24 @@ extern "C" int asr_colsum(const float *A, int M, int N, int64_t s0, int64_t s1, 
     ASR_CHECK_ARG(M >= 0 && N > 0, "colsum: bad shape");
     if (d <= 0) d = 0x7fffffff;
     hipStream_t st = (hipStream_t)stream;
-    const int strips = cdiv(M > 0 ? M : 1, CS_ROWS);
+    const int strips = colsum_strips(M, N);
     if (strips == 1 || part == nullptr) {
         hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(N, 64), 1), dim3(256), 0, st, A, M, N, s0, s1, d, out,
                            accumulate, M > 0 ? M : 1);
     } else {
-        hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(N, 64), strips), dim3(256), 0, st, A, M, N, s0, s1, d,
-                           part, 0, CS_ROWS);
-        hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(N, 64), 1), dim3(256), 0, st, part, strips, N,
-                           (int64_t)N, (int64_t)0, 0x7fffffff, out, accumulate, strips);
+        const int rows = cdiv(M, strips);
+        const int used = cdiv(M, rows);
+        ASR_CHECK_ARG(used <= 65535, "colsum: too many strips");
+        hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(N, 64), used), dim3(256), 0, st, A, M, N, s0, s1, d,
+                           part, 0, rows);
+        hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(N, 64), 1), dim3(256), 0, st, part, used, N,
+                           (int64_t)N, (int64_t)0, 0x7fffffff, out, accumulate, used);
     }
     ASR_CHECK_LAUNCH("colsum_kernel");
     return ASR_OK;
 }
 
-extern "C" int64_t asr_colsum_ws_floats(int M, int N) { return (int64_t)cdiv(M > 0 ? M : 1, CS_ROWS) * N; }
+extern "C" int64_t asr_colsum_ws_floats(int M, int N) { return (int64_t)colsum_strips(M, N) * N; }
 
 // ------------------------------------------------------------- transpose --
 __global__ __launch_bounds__(256) void transpose_kernel(const float *__restrict__ in,
