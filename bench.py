@@ -9,6 +9,7 @@ workload: BASELINE config 2: B=32 per GPU, 80-dim fbank,
           T_mel = linspace(1500, 900, 32), frame stacking 3 (T=500, D=240),
           5-layer BLSTM H=320, V=1000, L=100, fp32, synthetic N(0,1) features,
           random-init weights (seed 1234), inputs resident in HBM.
+Beside it, not part of `value`: `config5_conformer` = the same step for BASELINE config 5 (Conformer encoder).
 A "step" is one such pass over one batch.  For N > 1 it is launched by
 torch.distributed.run, one rank per GPU, each rank its own batch (weak scaling),
 gradients all-reduced in buckets on RCCL (asr_amd/parallel.py).
@@ -178,12 +179,70 @@ def roofline_probe(hp, dev):
     return out
 
 
+def config5_probe(dev, steps=5, warmup=2):
+    """BASELINE config 5 beside the headline (not part of `value`): AttModel(encoder_type='Conformer') --
+    TransformerEncoder(80, 256, 16, 4, 0.1), Models/AttModel.py:17 -- B=32, T_mel linspace(1500, 900) -> 374
+    subsampled frames, V=1000, L=100, dropout as the reference trains; forward + label-smoothed CE + backward."""
+    import types
+    from asr_amd.Loss.label_smoothing import label_smoothing_loss
+    from asr_amd.Models.AttModel import AttModel
+    B, Tm, V, L = 32, 1500, 1000, 100
+    hp = types.SimpleNamespace(lmfb_dim=80, frame_stacking=1, num_hidden_nodes=320, num_hidden_nodes_encoder=256,
+                               num_hidden_nodes_decoder=320, num_encoder_layer=5, encoder_dropout=0.2,
+                               encoder_type="Conformer", decoder_type="Attention", num_classes=V, eos_id=1,
+                               T_norm=True, B_norm=False, beam_width=1, max_decoder_seq_len=200,
+                               score_func="log_softmax")
+    torch.manual_seed(1234)
+    m = AttModel(hp).to(dev).train()
+    g = torch.Generator().manual_seed(1234)
+    lens = torch.linspace(1500, 900, B).long()
+    x = torch.randn(B, Tm, 80, generator=g)
+    src_pos = torch.zeros(B, Tm, dtype=torch.int64)
+    for b in range(B):
+        x[b, lens[b]:] = 0
+        src_pos[b, :lens[b]] = torch.arange(1, int(lens[b]) + 1)
+    tl = torch.linspace(100, 50, B).long()
+    tgt = torch.randint(0, V, (B, L), generator=g)
+    for b in range(B):
+        tgt[b, tl[b]:] = 0
+    x, src_pos, tgt, tl_d = x.to(dev), src_pos.to(dev), tgt.to(dev), tl.to(dev)
+
+    def step():
+        m.zero_grad(set_to_none=True)
+        loss = label_smoothing_loss(m(x, lens, tgt, src_pos), tgt, tl_d, hp.T_norm, hp.B_norm)
+        loss.backward()
+        return loss
+
+    # the side stream pays off under the BLSTM's latency-bound recurrences; this encoder is GEMM-bound and
+    # the decoder's weight gradients gain nothing from sharing CUs with it (88.6 ms off, 89.9 ms on)
+    from asr_amd import streams
+    was = streams.ENABLED
+    streams.enable(False)
+    try:
+        for _ in range(warmup):
+            step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            loss = step()
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / steps * 1e3
+    finally:
+        streams.enable(was)
+    n_par = sum(p.numel() for p in m.parameters())
+    return {"workload": "BASELINE config 5: Conformer x16 d256 h4 + attention decoder 320, B=32, T_mel linspace(1500,900) "
+                        "-> T'=374, V=1000, L=100, fp32, dropout 0.1",
+            "ms_per_step": ms, "frames_per_s": float(lens.sum()) / (ms * 1e-3), "steps": steps, "warmup": warmup,
+            "parameters": n_par, "loss": float(loss.detach())}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-config5", action="store_true", help="skip the Conformer (config 5) side measurement")
     ap.add_argument("--dropout", type=float, default=0.2, help="encoder dropout (template default 0.2)")
     args = ap.parse_args()
 
@@ -316,6 +375,11 @@ def main():
         if probes:
             res["roofline"] = dict(probes["blstm_fwd"])
             res["roofline_all"] = probes
+        if world == 1 and not args.no_config5:
+            try:
+                res["config5_conformer"] = config5_probe(dev)
+            except Exception as e:      # a side measurement must never cost the headline line
+                res["config5_conformer"] = {"error": repr(e)[:300]}
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(make_hp(encoder_dropout=0.0))
         print(json.dumps(res), flush=True)
