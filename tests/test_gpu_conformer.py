@@ -154,8 +154,20 @@ def test_attmodel_conformer_branch_vs_oracle():
     loss = label_smoothing_loss(y, targets.to(dev), tl.to(dev))
     loss.backward()
     assert rel_err(y.detach().cpu(), yr.detach()) < 1e-4
-    assert abs(float(loss) - float(lr)) / abs(float(lr)) < 1e-4
+    assert abs(float(loss.detach()) - float(lr.detach())) / abs(float(lr.detach())) < 1e-4
     want = dict(ref.named_parameters())
     floor = 5e-2 * max(float(p.grad.abs().max()) for p in want.values())
     for k, p in m.named_parameters():
         assert grad_err(p.grad.cpu(), want[k].grad, floor) < 1e-3, k
+    # greedy and beam decode through the same branch (Models/AttModel.py:31-39): eval mode, batch 1, src_pos passed on
+    m.eval()
+    ref.eval()
+    hp.max_decoder_seq_len = 6
+    with torch.no_grad():
+        hr = ref.encoder(x[:1], src_pos[:1])
+    _, raw = ref.decoder.decode_greedy(hr, lengths[:1], 6, eos_id=-1)
+    hp.beam_width, hp.eos_id = 1, raw[2]
+    assert m.decode(x[:1].to(dev), lengths[:1], None, src_pos[:1].to(dev)) == raw[:raw.index(raw[2]) + 1]
+    hp.beam_width = 3
+    want, _ = ref.decoder.decode_beam(hr, lengths[:1], 3, 6, hp.eos_id)
+    assert m.decode(x[:1].to(dev), lengths[:1], None, src_pos[:1].to(dev)) == want
