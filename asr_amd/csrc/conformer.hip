@@ -53,7 +53,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float *__restrict__ x
 
 // dx = rstd (gy - mean(gy) - xhat mean(gy xhat)), gy = dy gamma; per-block partial sums of
 // dy xhat (d gamma) and dy (d beta) go to part[block][2][d] for a deterministic second stage.
-#define LN_BWD_ROWS 16
+#define LN_BWD_ROWS 8
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const float *__restrict__ dy, const float *__restrict__ x,
                                                      const float *__restrict__ g, const float *__restrict__ mean,
                                                      const float *__restrict__ rstd, float *__restrict__ dx,
@@ -325,17 +325,23 @@ __global__ __launch_bounds__(256) void dwconv_bwd_w_kernel(const float *__restri
 #pragma unroll
     for (int k = 0; k < DW_K; ++k) acc[k] = 0.f;
     if (c < C) {
+        // the wave's 16 gradient frames and the 46 input frames they touch, loaded once into registers
+        constexpr int NF = DWW_FRAMES / 4;
         const float *xb = x + (int64_t)b * T * C + c;
         const float *db = dy + (int64_t)b * T * C + c;
-        const int tb = ch * DWW_FRAMES + w * (DWW_FRAMES / 4);
-        for (int t = tb; t < min(T, tb + DWW_FRAMES / 4); ++t) {
-            const float g = db[(int64_t)t * C];
+        const int tb = ch * DWW_FRAMES + w * NF;
+        float g[NF], xw[NF + DW_K - 1];
 #pragma unroll
-            for (int k = 0; k < DW_K; ++k) {
-                const int ti = t + k - DW_K / 2;
-                if (ti >= 0 && ti < T) acc[k] += g * xb[(int64_t)ti * C];
-            }
+        for (int o = 0; o < NF; ++o) g[o] = tb + o < T ? db[(int64_t)(tb + o) * C] : 0.f;
+#pragma unroll
+        for (int i = 0; i < NF + DW_K - 1; ++i) {
+            const int ti = tb - DW_K / 2 + i;
+            xw[i] = (ti >= 0 && ti < T) ? xb[(int64_t)ti * C] : 0.f;
         }
+#pragma unroll
+        for (int o = 0; o < NF; ++o)
+#pragma unroll
+            for (int k = 0; k < DW_K; ++k) acc[k] += g[o] * xw[o + k];
     }
 #pragma unroll
     for (int k = 0; k < DW_K; ++k) red[w][k][lane] = acc[k];
@@ -626,6 +632,50 @@ __global__ __launch_bounds__(256) void im2col_3x3s2_kernel(const float *__restri
         col[e0] = x[((b * Ti + 2 * to + ki) * Fi + 2 * fo + kj) * Cin + cin];
     }
 }
+// 16-byte version for Cin % 4 == 0 and ld == 9 Cin (the second convolution: 2.1 GB of patches)
+__global__ __launch_bounds__(256) void im2col_3x3s2_v4_kernel(const float4 *__restrict__ x, float4 *__restrict__ col,
+                                                              int Ti, int Fi, int C4, int To, int Fo, int64_t n4) {
+    FOR_EACH(e, n4) {
+        const int c4 = (int)(e % C4);
+        int64_t q = e / C4;
+        const int kj = (int)(q % 3); q /= 3;
+        const int ki = (int)(q % 3); q /= 3;
+        const int fo = (int)(q % Fo); q /= Fo;
+        const int to = (int)(q % To);
+        const int64_t b = q / To;
+        col[e] = x[((b * Ti + 2 * to + ki) * Fi + 2 * fo + kj) * C4 + c4];
+    }
+}
+__global__ __launch_bounds__(256) void col2im_3x3s2_v4_kernel(const float4 *__restrict__ dcol, const float4 *__restrict__ y,
+                                                              float4 *__restrict__ dx, int Ti, int Fi, int C4, int To,
+                                                              int Fo, int64_t n4) {
+    FOR_EACH(e, n4) {
+        const int c = (int)(e % C4);
+        int64_t q = e / C4;
+        const int fi = (int)(q % Fi); q /= Fi;
+        const int ti = (int)(q % Ti);
+        const int64_t b = q / Ti;
+        float4 acc = zero4();
+#pragma unroll
+        for (int ki = 0; ki < 3; ++ki) {
+            const int t2 = ti - ki;
+            if (t2 < 0 || (t2 & 1) || t2 / 2 >= To) continue;
+#pragma unroll
+            for (int kj = 0; kj < 3; ++kj) {
+                const int f2 = fi - kj;
+                if (f2 < 0 || (f2 & 1) || f2 / 2 >= Fo) continue;
+                const float4 v = dcol[(((b * To + t2 / 2) * Fo + f2 / 2) * 9 + ki * 3 + kj) * C4 + c];
+                acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+            }
+        }
+        if (y) {
+            const float4 m = y[e];
+            acc.x = m.x > 0.f ? acc.x : 0.f; acc.y = m.y > 0.f ? acc.y : 0.f;
+            acc.z = m.z > 0.f ? acc.z : 0.f; acc.w = m.w > 0.f ? acc.w : 0.f;
+        }
+        dx[e] = acc;
+    }
+}
 // the data gradient as a gather: dx[b,ti,fi,c] = sum over the (ki, kj) whose output position exists
 __global__ __launch_bounds__(256) void col2im_3x3s2_kernel(const float *__restrict__ dcol, const float *__restrict__ y,
                                                            float *__restrict__ dx, int Ti, int Fi, int Cin, int To, int Fo,
@@ -656,6 +706,12 @@ extern "C" int asr_im2col_3x3s2(const float *x, float *col, int B, int Ti, int F
     ASR_CHECK_ARG(x && col && B > 0 && Ti >= 3 && Fi >= 3 && Cin > 0 && ld >= 9 * Cin, "im2col_3x3s2: bad argument");
     const int To = (Ti - 3) / 2 + 1, Fo = (Fi - 3) / 2 + 1;
     const int64_t n = (int64_t)B * To * Fo * ld;
+    if (Cin % 4 == 0 && ld == 9 * Cin && (((uintptr_t)x | (uintptr_t)col) & 15) == 0) {
+        hipLaunchKernelGGL(im2col_3x3s2_v4_kernel, dim3(GRID1D(n / 4)), dim3(256), 0, (hipStream_t)stream,
+                           (const float4 *)x, (float4 *)col, Ti, Fi, Cin / 4, To, Fo, n / 4);
+        ASR_CHECK_LAUNCH("im2col_3x3s2_v4_kernel");
+        return ASR_OK;
+    }
     hipLaunchKernelGGL(im2col_3x3s2_kernel, dim3(GRID1D(n)), dim3(256), 0, (hipStream_t)stream, x, col, Ti, Fi, Cin, To,
                        Fo, ld, n);
     ASR_CHECK_LAUNCH("im2col_3x3s2_kernel");
@@ -666,6 +722,12 @@ extern "C" int asr_col2im_3x3s2(const float *dcol, const float *y, float *dx, in
     ASR_CHECK_ARG(dcol && dx && B > 0 && Ti >= 3 && Fi >= 3 && Cin > 0, "col2im_3x3s2: bad argument");
     const int To = (Ti - 3) / 2 + 1, Fo = (Fi - 3) / 2 + 1;
     const int64_t n = (int64_t)B * Ti * Fi * Cin;
+    if (Cin % 4 == 0 && (((uintptr_t)dcol | (uintptr_t)dx | (uintptr_t)y) & 15) == 0) {
+        hipLaunchKernelGGL(col2im_3x3s2_v4_kernel, dim3(GRID1D(n / 4)), dim3(256), 0, (hipStream_t)stream,
+                           (const float4 *)dcol, (const float4 *)y, (float4 *)dx, Ti, Fi, Cin / 4, To, Fo, n / 4);
+        ASR_CHECK_LAUNCH("col2im_3x3s2_v4_kernel");
+        return ASR_OK;
+    }
     hipLaunchKernelGGL(col2im_3x3s2_kernel, dim3(GRID1D(n)), dim3(256), 0, (hipStream_t)stream, dcol, y, dx, Ti, Fi, Cin,
                        To, Fo, n);
     ASR_CHECK_LAUNCH("col2im_3x3s2_kernel");
