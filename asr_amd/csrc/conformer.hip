@@ -18,6 +18,8 @@ __device__ __forceinline__ float sigmoid_exact(float x) { return 1.0f / (1.0f + 
 // ------------------------------------------------------------- LayerNorm --
 // nn.LayerNorm(d) (:161,194,218,250): one wave per row, the row in registers (d <= 1024).
 #define LN_MAXV 16
+// NV = registers per lane (64 NV >= d): instantiated for 1, 2, 4, 8, 16 so a 256-wide row costs 4, not 16
+template <int NV>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const float *__restrict__ x, const float *__restrict__ g,
                                                      const float *__restrict__ b, float *__restrict__ y,
                                                      float *__restrict__ mean, float *__restrict__ rstd,
@@ -26,10 +28,10 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float *__restrict__ x
     const int lane = threadIdx.x & 63;
     if (r >= rows) return;
     const float *xr = x + r * d;
-    float v[LN_MAXV];
+    float v[NV];
     float s = 0.f;
 #pragma unroll
-    for (int i = 0; i < LN_MAXV; ++i) {
+    for (int i = 0; i < NV; ++i) {
         const int c = lane + i * 64;
         v[i] = c < d ? xr[c] : 0.f;
         s += v[i];
@@ -37,14 +39,14 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float *__restrict__ x
     const float mu = wave_sum(s) / d;
     float q = 0.f;
 #pragma unroll
-    for (int i = 0; i < LN_MAXV; ++i) {
+    for (int i = 0; i < NV; ++i) {
         const int c = lane + i * 64;
         const float t = c < d ? v[i] - mu : 0.f;
         q += t * t;
     }
     const float rs = rsqrtf(wave_sum(q) / d + eps);
 #pragma unroll
-    for (int i = 0; i < LN_MAXV; ++i) {
+    for (int i = 0; i < NV; ++i) {
         const int c = lane + i * 64;
         if (c < d) y[r * d + c] = (v[i] - mu) * rs * g[c] + b[c];
     }
@@ -53,17 +55,18 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float *__restrict__ x
 
 // dx = rstd (gy - mean(gy) - xhat mean(gy xhat)), gy = dy gamma; per-block partial sums of
 // dy xhat (d gamma) and dy (d beta) go to part[block][2][d] for a deterministic second stage.
-#define LN_BWD_ROWS 8
+#define LN_BWD_ROWS 16
+template <int NV>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const float *__restrict__ dy, const float *__restrict__ x,
                                                      const float *__restrict__ g, const float *__restrict__ mean,
                                                      const float *__restrict__ rstd, float *__restrict__ dx,
                                                      float *__restrict__ part, int64_t rows, int d, const float *__restrict__ res) {
-    __shared__ float red[4][2][64 * LN_MAXV / 4];   // used in d-sized slices, see below
+    __shared__ float red[4][2][256];   // 256 columns at a time
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int64_t r0 = (int64_t)blockIdx.x * LN_BWD_ROWS;
-    float gg[LN_MAXV], dg[LN_MAXV], db[LN_MAXV];
+    float gg[NV], dg[NV], db[NV];
 #pragma unroll
-    for (int i = 0; i < LN_MAXV; ++i) {
+    for (int i = 0; i < NV; ++i) {
         const int c = lane + i * 64;
         gg[i] = c < d ? g[c] : 0.f;
         dg[i] = 0.f;
@@ -71,10 +74,10 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float *__restrict__ d
     }
     for (int64_t r = r0 + w; r < min(rows, r0 + LN_BWD_ROWS); r += 4) {
         const float mu = mean[r], rs = rstd[r];
-        float xh[LN_MAXV], gy[LN_MAXV];
+        float xh[NV], gy[NV];
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-        for (int i = 0; i < LN_MAXV; ++i) {
+        for (int i = 0; i < NV; ++i) {
             const int c = lane + i * 64;
             const float dyv = c < d ? dy[r * d + c] : 0.f;
             xh[i] = c < d ? (x[r * d + c] - mu) * rs : 0.f;
@@ -87,7 +90,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float *__restrict__ d
         s1 = wave_sum(s1) / d;
         s2 = wave_sum(s2) / d;
 #pragma unroll
-        for (int i = 0; i < LN_MAXV; ++i) {
+        for (int i = 0; i < NV; ++i) {
             const int c = lane + i * 64;
             if (c < d) {
                 float v = rs * (gy[i] - s1 - xh[i] * s2);
@@ -98,13 +101,14 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float *__restrict__ d
     }
     // cross-wave sum of the column partials, 256 columns at a time
     float *out = part + (int64_t)blockIdx.x * 2 * d;
-    for (int i0 = 0; i0 < LN_MAXV; i0 += 4) {
+#pragma unroll
+    for (int i0 = 0; i0 < NV; i0 += 4) {
         if (i0 * 64 >= d) break;
         __syncthreads();
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            red[w][0][i * 64 + lane] = dg[i0 + i];
-            red[w][1][i * 64 + lane] = db[i0 + i];
+            red[w][0][i * 64 + lane] = i0 + i < NV ? dg[i0 + i < NV ? i0 + i : 0] : 0.f;
+            red[w][1][i * 64 + lane] = i0 + i < NV ? db[i0 + i < NV ? i0 + i : 0] : 0.f;
         }
         __syncthreads();
         const int c = i0 * 64 + threadIdx.x;
@@ -120,8 +124,12 @@ extern "C" int asr_layernorm_fwd(const float *x, const float *gamma, const float
     ASR_CHECK_ARG(x && gamma && beta && y && mean && rstd, "layernorm_fwd: null pointer");
     ASR_CHECK_ARG(rows >= 0 && d > 0 && d <= 64 * LN_MAXV, "layernorm_fwd: d must be in [1, %d]", 64 * LN_MAXV);
     if (rows == 0) return ASR_OK;
-    hipLaunchKernelGGL(ln_fwd_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, x, gamma, beta, y, mean,
-                       rstd, rows, d, eps);
+#define LN_FWD(NV_)                                                                                              \
+    hipLaunchKernelGGL((ln_fwd_kernel<NV_>), dim3(cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, x, gamma, beta, \
+                       y, mean, rstd, rows, d, eps)
+    if (d <= 64) LN_FWD(1); else if (d <= 128) LN_FWD(2); else if (d <= 256) LN_FWD(4);
+    else if (d <= 512) LN_FWD(8); else LN_FWD(16);
+#undef LN_FWD
     ASR_CHECK_LAUNCH("ln_fwd_kernel");
     return ASR_OK;
 }
@@ -131,8 +139,12 @@ extern "C" int asr_layernorm_bwd(const float *dy, const float *x, const float *g
                                  void *stream) {
     ASR_CHECK_ARG(dy && x && gamma && mean && rstd && dx && part, "layernorm_bwd: null pointer");
     ASR_CHECK_ARG(rows > 0 && d > 0 && d <= 64 * LN_MAXV, "layernorm_bwd: bad shape");
-    hipLaunchKernelGGL(ln_bwd_kernel, dim3((unsigned)asr_layernorm_bwd_blocks(rows)), dim3(256), 0, (hipStream_t)stream,
-                       dy, x, gamma, mean, rstd, dx, part, rows, d, res);
+#define LN_BWD(NV_)                                                                                          \
+    hipLaunchKernelGGL((ln_bwd_kernel<NV_>), dim3((unsigned)asr_layernorm_bwd_blocks(rows)), dim3(256), 0,       \
+                       (hipStream_t)stream, dy, x, gamma, mean, rstd, dx, part, rows, d, res)
+    if (d <= 64) LN_BWD(1); else if (d <= 128) LN_BWD(2); else if (d <= 256) LN_BWD(4);
+    else if (d <= 512) LN_BWD(8); else LN_BWD(16);
+#undef LN_BWD
     ASR_CHECK_LAUNCH("ln_bwd_kernel");
     return ASR_OK;
 }

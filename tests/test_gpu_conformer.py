@@ -171,3 +171,24 @@ def test_attmodel_conformer_branch_vs_oracle():
     hp.beam_width = 3
     want, _ = ref.decoder.decode_beam(hr, lengths[:1], 3, 6, hp.eos_id)
     assert m.decode(x[:1].to(dev), lengths[:1], None, src_pos[:1].to(dev)) == want
+
+
+@pytest.mark.parametrize("rows,d", [(37, 100), (50, 300), (9, 700), (5, 1024), (130, 64)])
+def test_layernorm_kernels_all_widths(rows, d):
+    """asr_layernorm_fwd / _bwd at widths that exercise every register-count instantiation (d <= 64 ... 1024),
+    against torch.nn.functional.layer_norm in float64; the backward adds the residual-path gradient."""
+    from asr_amd.Models.Transformer_encoder import _ln_bwd, _ln_fwd
+    dev = _dev()
+    torch.manual_seed(d)
+    x, g, b = torch.randn(rows, d), torch.randn(d), torch.randn(d)
+    dy, res = torch.randn(rows, d), torch.randn(rows, d)
+    xr = x.double().requires_grad_(True)
+    gr, br = g.double().requires_grad_(True), b.double().requires_grad_(True)
+    yr = torch.nn.functional.layer_norm(xr, (d,), gr, br, 1e-5)
+    yr.backward(dy.double())
+    y, mean, rstd = _ln_fwd(x.to(dev), g.to(dev), b.to(dev))
+    assert rel_err(y.cpu(), yr.detach()) < 1e-5
+    dx, dg, db = _ln_bwd(dy.to(dev), x.to(dev), g.to(dev), mean, rstd, res.to(dev))
+    assert rel_err(dx.cpu(), xr.grad + res.double()) < 1e-5
+    assert rel_err(dg.cpu(), gr.grad) < 1e-5
+    assert rel_err(db.cpu(), br.grad) < 1e-5
