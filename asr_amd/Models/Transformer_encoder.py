@@ -84,14 +84,19 @@ def _linear(x2, W2, b=None, act=0):
     return y
 
 
-def _linear_bwd(dy2, x2, W2, bias=True, dx_out=None, accumulate=False):
-    """Returns (dx, dW, db) of y = x W^T + b; dx is written (or added) into dx_out when given."""
+def _linear_bwd(dy2, x2, W2, bias=True, dx_out=None, accumulate=False, sums=None):
+    """Returns (dx, dW, db) of y = x W^T + b; dx is written (or added) into dx_out when given.  With ``sums`` (a
+    list) the bias gradient is only queued there as (dy2, db): the caller sums all of a block's bias gradients
+    with one ops.colsum_multi call once the block's backward has produced them."""
     dW = torch.empty_like(W2)
     ops.matmul_tn(dy2, x2, dW)
     db = None
     if bias:
         db = _e(W2.shape[0], like=x2)
-        ops.colsum(dy2, db)
+        if sums is not None:
+            sums.append((dy2, db))
+        else:
+            ops.colsum(dy2, db)
     dx = dx_out if dx_out is not None else _e(dy2.shape[0], W2.shape[1], like=x2)
     ops.matmul_nn(dy2, W2, dx, accumulate=accumulate)
     return dx, dW, db
@@ -159,12 +164,14 @@ class _FFFunction(torch.autograd.Function):
         x2, ln_w, w1, w2, mean, rstd, h, a, s = ctx.saved_tensors
         p, m1, m_o, f = ctx.aux
         dy2 = dy.contiguous().view_as(x2)
+        sums = []
         do = _scale_mask(dy2, m_o, f)
-        ds, dW2, db2 = _linear_bwd(do, s, w2)
+        ds, dW2, db2 = _linear_bwd(do, s, w2, sums=sums)
         da = torch.empty_like(a)
         check(lib.asr_swish_bwd(ds.data_ptr(), a.data_ptr(), m1.data_ptr() if m1 is not None else 0, da.data_ptr(),
                                 a.numel(), C.c_float(p if m1 is not None else 0.0), _st()))
-        dh, dW1, db1 = _linear_bwd(da, h, w1)
+        dh, dW1, db1 = _linear_bwd(da, h, w1, sums=sums)
+        ops.colsum_multi(sums)
         dx, dg, dbeta = _ln_bwd(dh, x2, ln_w, mean, rstd, dy2)
         return dx.view_as(dy), dg, dbeta, dW1, db1, dW2, db2, None, None, None, None
 
@@ -224,8 +231,9 @@ class _RelAttnFunction(torch.autograd.Function):
         Tp = _pad4(T)
         proj, score, posp = (d, dk, T * d), (Tp, T * Tp, H * T * Tp), (d, dk, 0)
         dy2 = dy.contiguous().view_as(x2)
+        sums = []
         do = _scale_mask(dy2, m_o, f_o)
-        dcx, dWo, dbo = _linear_bwd(do, cx, wo)
+        dcx, dWo, dbo = _linear_bwd(do, cx, wo, sums=sums)
         dattn = _e(B, H, T, Tp, like=x2)
         _head_gemm(dcx, vv, dattn, T, T, dk, H, B, a=proj, b=proj, c=score)                       # d attn = d ctx v^T
         dvv = torch.empty_like(vv)
@@ -245,12 +253,12 @@ class _RelAttnFunction(torch.autograd.Function):
         ops.sgemm(dbd, qv, dpp, T, dk, B * T, a_mode=1, b_mode=1, a_two=(T, Tp, H * T * Tp), b_stride=d, c_stride=d,
                   nbatch=H, batch_a=T * Tp, batch_b=dk, batch_c=dk, pad_ok=1, splitk=sk)
         du, dv = _e(d, like=x2), _e(d, like=x2)
-        ops.colsum(dqu, du)
-        ops.colsum(dqv, dv)
+        sums += [(dqu, du), (dqv, dv)]
         dq = _axpby(dqu, dqv, 1.0, 1.0)
-        dh, dWq, dbq = _linear_bwd(dq, h, wq)
-        _, dWk, dbk = _linear_bwd(dkk, h, wk, dx_out=dh, accumulate=True)
-        _, dWv, dbv = _linear_bwd(dvv, h, wv, dx_out=dh, accumulate=True)
+        dh, dWq, dbq = _linear_bwd(dq, h, wq, sums=sums)
+        _, dWk, dbk = _linear_bwd(dkk, h, wk, dx_out=dh, accumulate=True, sums=sums)
+        _, dWv, dbv = _linear_bwd(dvv, h, wv, dx_out=dh, accumulate=True, sums=sums)
+        ops.colsum_multi(sums)                                              # six bias gradients, two launches
         dWpos = torch.empty_like(wpos)
         ops.matmul_tn(dpp, pe, dWpos)
         dx, dg, dbeta = _ln_bwd(dh, x2, nw, mean, rstd, dy2)
@@ -305,8 +313,9 @@ class _ConvModuleFunction(torch.autograd.Function):
         rows = B * T
         W1, Wd, Wc, W2 = pw1w.view(2 * d, d), dww.view(d, KSIZE), cow.view(d, d), pw2w.view(d, d)
         dy2 = dy.contiguous().view_as(x2)
+        bias_sums = []
         do = _scale_mask(dy2, m_o, f_o)
-        ds, dW2, db2 = _linear_bwd(do, s, W2)
+        ds, dW2, db2 = _linear_bwd(do, s, W2, sums=bias_sums)
         part = _e(int(lib.asr_bn_blocks(rows)), 2 * d, like=x2)
         check(lib.asr_bn_swish_bwd_part(ds.data_ptr(), c2.data_ptr(), msum.data_ptr(), vsum.data_ptr(), C.c_float(ms),
                                         C.c_float(vs), bnw.data_ptr(), bnb.data_ptr(), part.data_ptr(), rows, d, LN_EPS, _st()))
@@ -316,9 +325,9 @@ class _ConvModuleFunction(torch.autograd.Function):
         check(lib.asr_bn_swish_bwd(ds.data_ptr(), c2.data_ptr(), msum.data_ptr(), vsum.data_ptr(), C.c_float(ms),
                                    C.c_float(vs), bnw.data_ptr(), bnb.data_ptr(), sums.data_ptr() if training else 0,
                                    dc2.data_ptr(), rows, d, LN_EPS, _st()))
-        dc1, dWc, dbc = _linear_bwd(dc2, c1, Wc)
+        dc1, dWc, dbc = _linear_bwd(dc2, c1, Wc, sums=bias_sums)
         ddb = _e(d, like=x2)
-        ops.colsum(dc1, ddb)
+        bias_sums.append((dc1, ddb))
         wpart = _e(int(lib.asr_dwconv_bwd_w_chunks(B, T)), KSIZE * d, like=x2)
         check(lib.asr_dwconv_bwd_w(dc1.data_ptr(), g.data_ptr(), wpart.data_ptr(), B, T, d, KSIZE, _st()))
         dwkc = _e(KSIZE, d, like=x2)
@@ -328,7 +337,8 @@ class _ConvModuleFunction(torch.autograd.Function):
         check(lib.asr_dwconv(dc1.data_ptr(), Wd.data_ptr(), 0, dg.data_ptr(), B, T, d, KSIZE, 1, _st()))
         da = torch.empty_like(a)
         check(lib.asr_glu_bwd(dg.data_ptr(), a.data_ptr(), da.data_ptr(), rows, d, _st()))
-        dh, dW1, db1 = _linear_bwd(da, h, W1)
+        dh, dW1, db1 = _linear_bwd(da, h, W1, sums=bias_sums)
+        ops.colsum_multi(bias_sums)
         dx, dgam, dbeta = _ln_bwd(dh, x2, lnw, mean, rstd, dy2)
         return (dx.view_as(dy), dgam, dbeta, dW1.view_as(pw1w), db1, dWd.view_as(dww), ddb, dWc.view_as(cow), dbc,
                 sums[d:], sums[:d], dW2.view_as(pw2w), db2, None, None, None, None)

@@ -40,6 +40,14 @@ class GemmDesc(C.Structure):
 TENSOR_LIST_MAX = 48
 
 
+COLSUM_LIST_MAX = 8
+
+
+class ColsumList(C.Structure):
+    _fields_ = [("count", C.c_int), ("src", c_f * COLSUM_LIST_MAX), ("out", c_f * COLSUM_LIST_MAX),
+                ("n", C.c_int * COLSUM_LIST_MAX), ("off", c_i64 * COLSUM_LIST_MAX)]
+
+
 class TensorList(C.Structure):
     _fields_ = [("count", C.c_int), ("p", c_f * TENSOR_LIST_MAX), ("n", c_i64 * TENSOR_LIST_MAX)]
 
@@ -76,6 +84,8 @@ SYMBOLS = {
     "asr_sgemm": (C.c_int, [C.POINTER(GemmDesc), c_f]),
     "asr_colsum": (C.c_int, [c_f, C.c_int, C.c_int, c_i64, c_i64, C.c_int, c_f, C.c_int, c_f, c_f]),
     "asr_colsum_ws_floats": (c_i64, [C.c_int, C.c_int]),
+    "asr_colsum_multi_ws_floats": (c_i64, [C.POINTER(ColsumList), C.c_int]),
+    "asr_colsum_multi": (C.c_int, [C.POINTER(ColsumList), C.c_int, c_f, c_f]),
     "asr_transpose": (C.c_int, [c_f, c_f, C.c_int, C.c_int, C.c_int, c_f]),
     "asr_scatter_rows": (C.c_int, [c_f, c_f, C.c_int, C.c_int, c_i64, c_f, C.c_int, c_f]),
     "asr_mul_dtanh": (C.c_int, [c_f, c_f, c_f, c_i64, c_f]),

@@ -86,6 +86,73 @@ extern "C" int asr_colsum(const float *A, int M, int N, int64_t s0, int64_t s1, 
 
 extern "C" int64_t asr_colsum_ws_floats(int M, int N) { return (int64_t)colsum_strips(M, N) * N; }
 
+// Several column sums over matrices of the same height in two launches (all the bias gradients of
+// one block of the Conformer backward: their producers finish at different times, their sums do not
+// depend on each other).  Row-major contiguous sources (row stride = n[i]).
+__global__ __launch_bounds__(256) void colsum_multi_kernel(asr_colsum_list l, int M, int rows_per_block,
+                                                           float *__restrict__ part, int stage) {
+    __shared__ float sh[4][64];
+    const int z = blockIdx.z, N = l.n[z];
+    if ((int)blockIdx.x * 64 >= N) return;
+    const float *A = stage == 0 ? l.src[z] : part + l.off[z];
+    float *out = stage == 0 ? part + l.off[z] + (int64_t)blockIdx.y * N : l.out[z];
+    const int n = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int q = threadIdx.x >> 6;
+    const int m_begin = blockIdx.y * rows_per_block;
+    const int m_end = min(M, m_begin + rows_per_block);
+    float acc = 0.f;
+    if (n < N) {
+        float a8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        int m = m_begin + q;
+        for (; m + 28 < m_end; m += 32) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) a8[u] += A[(int64_t)(m + 4 * u) * N + n];
+        }
+        for (; m < m_end; m += 4) a8[0] += A[(int64_t)m * N + n];
+        acc = ((a8[0] + a8[1]) + (a8[2] + a8[3])) + ((a8[4] + a8[5]) + (a8[6] + a8[7]));
+    }
+    sh[q][threadIdx.x & 63] = acc;
+    __syncthreads();
+    if (q == 0 && n < N)
+        out[n] = (sh[0][threadIdx.x] + sh[1][threadIdx.x]) + (sh[2][threadIdx.x] + sh[3][threadIdx.x]);
+}
+
+static int colsum_multi_strips(const asr_colsum_list *l, int M) {
+    int colblocks = 0;
+    for (int i = 0; i < l->count; ++i) colblocks += cdiv(l->n[i], 64);
+    int strips = cdiv(1024, colblocks > 0 ? colblocks : 1);
+    const int max_strips = cdiv(M > 0 ? M : 1, 32);
+    if (strips > max_strips) strips = max_strips;
+    return strips < 1 ? 1 : strips;
+}
+extern "C" int64_t asr_colsum_multi_ws_floats(const asr_colsum_list *l, int M) {
+    if (!l || l->count <= 0 || l->count > ASR_COLSUM_LIST_MAX) return 0;
+    int64_t cols = 0;
+    for (int i = 0; i < l->count; ++i) cols += l->n[i];
+    return (int64_t)colsum_multi_strips(l, M) * cols;
+}
+extern "C" int asr_colsum_multi(const asr_colsum_list *lin, int M, float *part, void *stream) {
+    ASR_CHECK_ARG(lin && part, "colsum_multi: null pointer");
+    ASR_CHECK_ARG(lin->count > 0 && lin->count <= ASR_COLSUM_LIST_MAX && M > 0, "colsum_multi: bad list");
+    asr_colsum_list l = *lin;
+    const int strips = colsum_multi_strips(&l, M);
+    const int rows = cdiv(M, strips), used = cdiv(M, rows);
+    int maxn = 0;
+    int64_t off = 0;
+    for (int i = 0; i < l.count; ++i) {
+        ASR_CHECK_ARG(l.src[i] && l.out[i] && l.n[i] > 0, "colsum_multi: bad entry %d", i);
+        l.off[i] = off;
+        off += (int64_t)used * l.n[i];
+        if (l.n[i] > maxn) maxn = l.n[i];
+    }
+    ASR_CHECK_ARG(used <= 65535, "colsum_multi: too many strips");
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(colsum_multi_kernel, dim3(cdiv(maxn, 64), used, l.count), dim3(256), 0, st, l, M, rows, part, 0);
+    hipLaunchKernelGGL(colsum_multi_kernel, dim3(cdiv(maxn, 64), 1, l.count), dim3(256), 0, st, l, used, used, part, 1);
+    ASR_CHECK_LAUNCH("colsum_multi_kernel");
+    return ASR_OK;
+}
+
 // ------------------------------------------------------------- transpose --
 __global__ __launch_bounds__(256) void transpose_kernel(const float *__restrict__ in,
                                                         float *__restrict__ out, int R, int C) {

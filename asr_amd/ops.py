@@ -139,6 +139,20 @@ def colsum(a2d, out, accumulate=False):
     check(lib.asr_colsum(_p(a2d), M, N, a2d.stride(0), 0, 0, _p(out), int(accumulate), _p(part), _stream()))
 
 
+def colsum_multi(pairs):
+    """pairs: [(a2d (M, n_i) contiguous, out (n_i,))...], all of the same height M, at most 8: two launches."""
+    lib = _lib.load()
+    l = _lib.ColsumList()
+    l.count = len(pairs)
+    M = pairs[0][0].shape[0]
+    for i, (a, out) in enumerate(pairs):
+        if a.shape[0] != M or not a.is_contiguous() or out.numel() != a.shape[1]:
+            raise RuntimeError("asr_amd.colsum_multi: matrices must be contiguous, of equal height, out of width n")
+        l.src[i], l.out[i], l.n[i] = a.data_ptr(), out.data_ptr(), a.shape[1]
+    part = torch.empty(int(lib.asr_colsum_multi_ws_floats(C.byref(l), M)), device=pairs[0][0].device, dtype=torch.float32)
+    check(lib.asr_colsum_multi(C.byref(l), M, _p(part), _stream()))
+
+
 def transpose(x2d):
     """Contiguous (R,C) -> new contiguous (C,R); leading dims are batched."""
     lib = _lib.load()

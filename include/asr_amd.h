@@ -163,6 +163,20 @@ int asr_sgemm(const asr_gemm_desc *d, void *stream);
 int asr_colsum(const float *A, int M, int N, int64_t s0, int64_t s1, int d,
                float *out, int accumulate, float *part, void *stream);
 int64_t asr_colsum_ws_floats(int M, int N);
+/* The same sum for up to ASR_COLSUM_LIST_MAX contiguous row-major matrices of equal height M
+ * (src[i] is M x n[i], out[i] gets n[i] sums; off is filled in by the library) in two launches: the
+ * bias gradients of one block of the Conformer backward (Models/Transformer_encoder.py, every
+ * nn.Linear / nn.Conv1d bias and pos_bias_u / pos_bias_v).  part: asr_colsum_multi_ws_floats floats. */
+#define ASR_COLSUM_LIST_MAX 8
+typedef struct {
+    int count;
+    const float *src[ASR_COLSUM_LIST_MAX];
+    float *out[ASR_COLSUM_LIST_MAX];
+    int n[ASR_COLSUM_LIST_MAX];
+    int64_t off[ASR_COLSUM_LIST_MAX];
+} asr_colsum_list;
+int64_t asr_colsum_multi_ws_floats(const asr_colsum_list *l, int M);
+int asr_colsum_multi(const asr_colsum_list *l, int M, float *part, void *stream);
 /* out[c*R + r] = in[r*C + c], nbatch matrices back to back */
 int asr_transpose(const float *in, float *out, int R, int C, int nbatch, void *stream);
 /* table[v][:] = sum_{i: idx[i]==v} src[i][:]  for every v < n_table_rows (embedding
