@@ -212,9 +212,13 @@ class _RelAttnFunction(torch.autograd.Function):
         _head_gemm(qu, k, attn, T, T, dk, H, B, a=proj, b=proj, c=score)      # (q + u) k^T          :97
         _head_gemm(qv, pp, bd, T, T, dk, H, B, a=proj, b=posp, c=score)       # (q + v) p^T          :98
         scale = 1.0 / math.sqrt(dk)
-        check(lib.asr_relattn_softmax_fwd(attn.data_ptr(), bd.data_ptr(), keep.data_ptr(), C.c_float(scale), B, H, T, Tp, _st()))
+        on = training and p > 0.0
+        attn_d = torch.empty_like(attn) if on else attn
+        m_att = torch.empty(attn.shape, device=x.device, dtype=torch.uint8) if on else None
+        check(lib.asr_relattn_softmax_fwd(attn.data_ptr(), bd.data_ptr(), keep.data_ptr(), C.c_float(scale), B, H, T, Tp,
+                                          attn_d.data_ptr() if on else 0, m_att.data_ptr() if on else 0,
+                                          C.c_float(p if on else 0.0), C.c_uint64(seed), _st()))
         del bd
-        attn_d, m_att = _drop(attn, p, training, seed)
         cx = _e(B * T, d, like=x)
         _head_gemm(attn_d, vv, cx, T, dk, T, H, B, a=score, b=proj, c=proj, b_mode=1)   # attn v   :136
         y, m_o, f_o = _residual_drop(x2, _linear(cx, wo, bo), 1.0, p, training, 1)
@@ -238,10 +242,10 @@ class _RelAttnFunction(torch.autograd.Function):
         _head_gemm(dcx, vv, dattn, T, T, dk, H, B, a=proj, b=proj, c=score)                       # d attn = d ctx v^T
         dvv = torch.empty_like(vv)
         _head_gemm(attn_d, dcx, dvv, T, dk, T, H, B, a=score, b=proj, c=proj, a_mode=1, b_mode=1, pad_ok=1)  # d v = attn^T d ctx
-        dattn = _drop_bwd(dattn, m_att, p)
         dbd = torch.empty_like(dattn)
         check(lib.asr_relattn_softmax_bwd(attn.data_ptr(), dattn.data_ptr(), dbd.data_ptr(), keep.data_ptr(),
-                                          C.c_float(scale), B, H, T, Tp, _st()))
+                                          C.c_float(scale), B, H, T, Tp, m_att.data_ptr() if m_att is not None else 0,
+                                          C.c_float(p if m_att is not None else 0.0), _st()))
         dqu, dkk, dqv = torch.empty_like(qu), torch.empty_like(k), torch.empty_like(qv)
         _head_gemm(dattn, k, dqu, T, dk, T, H, B, a=score, b=proj, c=proj, b_mode=1)               # d ac k
         _head_gemm(dattn, qu, dkk, T, dk, T, H, B, a=score, b=proj, c=proj, a_mode=1, b_mode=1, pad_ok=1)    # d ac^T (q + u)

@@ -141,8 +141,10 @@ SYMBOLS = {
                                         C.c_float, c_f]),
     "asr_bn_swish_bwd": (C.c_int, [c_f, c_f, c_f, c_f, C.c_float, C.c_float, c_f, c_f, c_f, c_f, c_i64, C.c_int,
                                    C.c_float, c_f]),
-    "asr_relattn_softmax_fwd": (C.c_int, [c_f, c_f, c_f, C.c_float, C.c_int, C.c_int, C.c_int, C.c_int, c_f]),
-    "asr_relattn_softmax_bwd": (C.c_int, [c_f, c_f, c_f, c_f, C.c_float, C.c_int, C.c_int, C.c_int, C.c_int, c_f]),
+    "asr_relattn_softmax_fwd": (C.c_int, [c_f, c_f, c_f, C.c_float, C.c_int, C.c_int, C.c_int, C.c_int, c_f, c_f,
+                                          C.c_float, C.c_uint64, c_f]),
+    "asr_relattn_softmax_bwd": (C.c_int, [c_f, c_f, c_f, c_f, C.c_float, C.c_int, C.c_int, C.c_int, C.c_int, c_f,
+                                          C.c_float, c_f]),
     "asr_im2col_3x3s2": (C.c_int, [c_f, c_f, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_f]),
     "asr_col2im_3x3s2": (C.c_int, [c_f, c_f, c_f, C.c_int, C.c_int, C.c_int, C.c_int, c_f]),
 }

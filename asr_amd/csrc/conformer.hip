@@ -515,7 +515,9 @@ extern "C" int asr_bn_swish_bwd(const float *dy, const float *x, const float *ms
 #define SM_MAXV 16
 __global__ __launch_bounds__(256) void relattn_softmax_fwd_kernel(float *__restrict__ ac, const float *__restrict__ bd,
                                                                   const uint8_t *__restrict__ keep, float scale, int H,
-                                                                  int T, int ld, int64_t nrows) {
+                                                                  int T, int ld, int64_t nrows, float *__restrict__ ad,
+                                                                  uint8_t *__restrict__ dmask, uint32_t thresh, float dscale,
+                                                                  uint64_t seed) {
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (row >= nrows) return;
@@ -550,14 +552,22 @@ __global__ __launch_bounds__(256) void relattn_softmax_fwd_kernel(float *__restr
 #pragma unroll
     for (int u = 0; u < SM_MAXV; ++u) {
         const int j = lane + u * 64;
-        if (j < T) a[j] = v[u] * inv;
-        else if (j < ld) a[j] = 0.f;          // the padding columns of the row stay zero
+        if (j >= ld) continue;
+        const float p = j < T ? v[u] * inv : 0.f;          // the padding columns of the row stay zero
+        a[j] = p;
+        if (ad) {                                         // the dropout on the map (:133-134) in the same pass
+            const int64_t e = row * ld + j;
+            const bool kp = asr_keep(seed, e, thresh);
+            dmask[e] = kp;
+            ad[e] = kp ? p * dscale : 0.f;
+        }
     }
 }
 // ds = attn (dattn - sum_j attn dattn) * scale, zero at masked keys; in place over dattn (= d ac)
 __global__ __launch_bounds__(256) void relattn_softmax_bwd_kernel(const float *__restrict__ attn, float *__restrict__ dattn,
                                                                   const uint8_t *__restrict__ keep, float scale, int H,
-                                                                  int T, int ld, int64_t nrows) {
+                                                                  int T, int ld, int64_t nrows,
+                                                                  const uint8_t *__restrict__ dmask, float dscale) {
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (row >= nrows) return;
@@ -571,6 +581,7 @@ __global__ __launch_bounds__(256) void relattn_softmax_bwd_kernel(const float *_
         const int j = lane + u * 64;
         pv[u] = j < T ? p[j] : 0.f;
         gv[u] = j < T ? g[j] : 0.f;
+        if (dmask && j < T) gv[u] = dmask[row * ld + j] ? gv[u] * dscale : 0.f;   // gradient of the map's dropout
         s += pv[u] * gv[u];
     }
     s = wave_sum(s);
@@ -600,24 +611,26 @@ __global__ __launch_bounds__(256) void relshift_bwd_kernel(const float *__restri
 }
 
 extern "C" int asr_relattn_softmax_fwd(float *ac, const float *bd, const uint8_t *keep, float scale, int B, int H, int T,
-                                       int ld, void *stream) {
+                                       int ld, float *attn_drop, uint8_t *drop_mask, float p, uint64_t seed, void *stream) {
+    ASR_CHECK_ARG((attn_drop == nullptr) == (drop_mask == nullptr) && p >= 0.f && p < 1.f, "relattn_softmax_fwd: bad dropout");
     ASR_CHECK_ARG(ac && bd && keep, "relattn_softmax_fwd: null pointer");
     ASR_CHECK_ARG(ld >= T && ld <= 64 * SM_MAXV, "relattn_softmax_fwd: bad row stride");
     ASR_CHECK_ARG(B > 0 && H > 0 && T > 0 && T <= 64 * SM_MAXV, "relattn_softmax_fwd: T must be in [1, %d]", 64 * SM_MAXV);
     const int64_t nrows = (int64_t)B * H * T;
     hipLaunchKernelGGL(relattn_softmax_fwd_kernel, dim3(cdiv(nrows, 4)), dim3(256), 0, (hipStream_t)stream, ac, bd, keep,
-                       scale, H, T, ld, nrows);
+                       scale, H, T, ld, nrows, attn_drop, drop_mask, drop_thresh(p), 1.0f / (1.0f - p), seed);
     ASR_CHECK_LAUNCH("relattn_softmax_fwd_kernel");
     return ASR_OK;
 }
 extern "C" int asr_relattn_softmax_bwd(const float *attn, float *dattn, float *dbd, const uint8_t *keep, float scale,
-                                       int B, int H, int T, int ld, void *stream) {
+                                       int B, int H, int T, int ld, const uint8_t *drop_mask, float p, void *stream) {
+    ASR_CHECK_ARG(p >= 0.f && p < 1.f, "relattn_softmax_bwd: bad dropout");
     ASR_CHECK_ARG(attn && dattn && dbd && keep, "relattn_softmax_bwd: null pointer");
     ASR_CHECK_ARG(ld >= T && ld <= 64 * SM_MAXV, "relattn_softmax_bwd: bad row stride");
     ASR_CHECK_ARG(B > 0 && H > 0 && T > 0 && T <= 64 * SM_MAXV, "relattn_softmax_bwd: T must be in [1, %d]", 64 * SM_MAXV);
     const int64_t nrows = (int64_t)B * H * T;
     hipLaunchKernelGGL(relattn_softmax_bwd_kernel, dim3(cdiv(nrows, 4)), dim3(256), 0, (hipStream_t)stream, attn, dattn,
-                       keep, scale, H, T, ld, nrows);
+                       keep, scale, H, T, ld, nrows, drop_mask, 1.0f / (1.0f - p));
     hipLaunchKernelGGL(relshift_bwd_kernel, dim3(GRID1D(nrows * ld)), dim3(256), 0, (hipStream_t)stream, dattn, dbd, T,
                        ld, nrows * ld);
     ASR_CHECK_LAUNCH("relattn_softmax_bwd_kernel");

@@ -345,11 +345,14 @@ int asr_bn_swish_bwd(const float *dy, const float *x, const float *msum, const f
  * softmax_j(keep[b,j] ? (ac + rel_shift(bd)) * scale : -1e4) in place, T <= 1024.  Backward: dattn
  * becomes d ac (= the shifted score gradient) in place and dbd its un-shifted copy.  All maps have
  * row stride ld >= T (a multiple of 4 lets the products that read them use 16-byte loads,
- * asr_gemm_desc.pad_ok); the kernels keep columns T..ld-1 at zero. */
+ * asr_gemm_desc.pad_ok); the kernels keep columns T..ld-1 at zero.
+ * attn_drop / drop_mask != NULL: the dropout on the map (:133-134) in the same pass -- attn_drop gets the
+ * dropped copy the value product reads, drop_mask its mask; the backward then takes the gradient w.r.t. the
+ * dropped map in dattn and applies the mask itself. */
 int asr_relattn_softmax_fwd(float *ac, const float *bd, const uint8_t *keep, float scale, int B, int H, int T,
-                            int ld, void *stream);
+                            int ld, float *attn_drop, uint8_t *drop_mask, float p, uint64_t seed, void *stream);
 int asr_relattn_softmax_bwd(const float *attn, float *dattn, float *dbd, const uint8_t *keep, float scale,
-                            int B, int H, int T, int ld, void *stream);
+                            int B, int H, int T, int ld, const uint8_t *drop_mask, float p, void *stream);
 /* CNN_embedding (:386-407): patches of nn.Conv2d(Cin, Cout, 3, 2) on a channels-last map
  * x (B,Ti,Fi,Cin): col (B*To*Fo, ld) in (ki,kj,cin) order, To = (Ti-3)/2+1, Fo = (Fi-3)/2+1, columns
  * 9*Cin..ld-1 zero (ld = 12 gives the first convolution, Cin = 1, 16-byte rows);

@@ -192,3 +192,43 @@ def test_layernorm_kernels_all_widths(rows, d):
     assert rel_err(dx.cpu(), xr.grad + res.double()) < 1e-5
     assert rel_err(dg.cpu(), gr.grad) < 1e-5
     assert rel_err(db.cpu(), br.grad) < 1e-5
+
+
+def test_dropout_backward_matches_finite_differences():
+    """With dropout 0.1 the masks come from seeds drawn from torch's CPU generator, so re-seeding reproduces them:
+    the analytic directional derivative (masks, 1/(1-p) factors, fused activation/residual/softmax dropouts) must
+    match a central finite difference of the same stochastic function (a lost 1/(1-p) would be an 11 % error)."""
+    z, meta = load_conf("conf_small")
+    dev = _dev()
+    m = _build(meta, conf_state(z), dropout=0.1).train()
+    src = torch.from_numpy(z["src"]).to(dev)
+    src_pos = torch.from_numpy(z["src_pos"]).to(dev)
+    R = torch.from_numpy(z["R"]).to(dev)
+
+    def loss():
+        torch.manual_seed(99)
+        return (m(src, src_pos) * R).sum()
+
+    a = loss()
+    b = loss()
+    assert torch.equal(a.detach(), b.detach())
+    m.zero_grad()
+    a.backward()
+    names = ["encoder.layers.0.ff_1.linear1.weight", "encoder.layers.0.attn.q_linear.weight",
+             "encoder.layers.1.conv_module.pointwise_conv1.weight", "encoder.layers.1.ff_2.linear2.weight",
+             "encoder.layers.0.attn.v_linear.weight"]
+    params = dict(m.named_parameters())
+    g = torch.Generator().manual_seed(5)
+    for n in names:
+        w = params[n]
+        v = torch.randn(w.shape, generator=g).to(dev)
+        analytic = float((w.grad * v).sum())
+        eps = 2e-3
+        with torch.no_grad():
+            w.add_(eps * v)
+            lp = float(loss())
+            w.sub_(2 * eps * v)
+            lm = float(loss())
+            w.add_(eps * v)
+        fd = (lp - lm) / (2 * eps)
+        assert abs(fd - analytic) < 3e-2 * max(abs(analytic), 1.0), (n, fd, analytic)
