@@ -368,10 +368,10 @@ extern "C" int asr_sgemm(const asr_gemm_desc *din, void *stream) {
     if (cfg == 2 && big && fast && splitk == 1 &&
         (int64_t)cdiv(d.M, 128) * cdiv(d.N, 64) * d.nbatch < 1024)
         cfg = 3;
-    if (big && fast && cfg == 1) {          // experiment: 64 x 128 tiles
+    if (big && fast && cfg == 1) {          // experiment: 64 x 128 tiles (no gain once measured on correct results)
         dim3 grid(cdiv(d.N, 128), cdiv(d.M, 64), d.nbatch * splitk);
         ASR_CHECK_ARG(grid.y <= 65535 && grid.z <= 65535, "sgemm: grid too large");
-        LAUNCH_MODES(64, 128, 16, true)
+        if (GK == 32) { LAUNCH_MODES(64, 128, 32, true) } else { LAUNCH_MODES(64, 128, 16, true) }
     } else if (big && fast && cfg == 2) {   // default: 128 x 64 tiles (more, smaller tiles: shorter tail)
         dim3 grid(cdiv(d.N, 64), cdiv(d.M, 128), d.nbatch * splitk);
         ASR_CHECK_ARG(grid.y <= 65535 && grid.z <= 65535, "sgemm: grid too large");

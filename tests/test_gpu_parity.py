@@ -30,7 +30,8 @@ def _build(hp, state):
 
 # ------------------------------------------------------------------ sgemm --
 @pytest.mark.parametrize("M,N,K", [(1, 1, 1), (5, 7, 3), (64, 64, 16), (130, 70, 33), (257, 129, 100),
-                                   (300, 260, 64), (1000, 384, 40), (2304, 1408, 50)])
+                                   (300, 260, 64), (1000, 384, 40), (2304, 1408, 50), (2304, 1408, 64),
+                                   (11968, 256, 256)])
 @pytest.mark.parametrize("a_mode,b_mode", [(0, 0), (0, 1), (1, 0), (1, 1)])
 def test_sgemm_modes(M, N, K, a_mode, b_mode):
     from asr_amd import ops
