@@ -233,3 +233,68 @@ def test_dropout_backward_matches_finite_differences():
         fd = (lp - lm) / (2 * eps)
         assert abs(fd - analytic) < 3e-2 * max(abs(analytic), 1.0), (n, fd, analytic)
 
+
+
+@pytest.mark.parametrize("T,lens", [(7, [7, 7]), (11, [11, 5]), (45, [45, 0]), (64, [3, 64])])
+def test_edge_lengths_vs_oracle(T, lens):
+    """Edges of the subsampling and the key mask against the CPU restatement: 7 frames -> one encoder frame
+    (T' = 1), 11 -> 2, an utterance with no valid frame at all (every key masked with -1e4: uniform attention, as the
+    reference computes it) and one whose valid part ends before the first subsampled frame boundary."""
+    from oracle import ref_conformer as RC
+    dev = _dev()
+    torch.manual_seed(T)
+    ref = RC.TransformerEncoder(20, 16, 2, 2, 0.0)
+    with torch.no_grad():
+        for k, p in ref.named_parameters():
+            if "norm" in k:
+                p.add_(0.1 * torch.randn_like(p))
+    B = len(lens)
+    src = torch.randn(B, T, 20)
+    src_pos = torch.zeros(B, T, dtype=torch.int64)
+    for b, n in enumerate(lens):
+        src[b, n:] = 0
+        src_pos[b, :n] = torch.arange(1, n + 1)
+    m = _build(dict(idim=20, d_model=16, N_e=2, heads=2), ref.state_dict())
+    ref.train()
+    m.train()
+    yr = ref(src, src_pos)
+    R = torch.randn_like(yr)
+    (yr * R).sum().backward()
+    y = m(src.to(dev), src_pos.to(dev))
+    assert y.shape == yr.shape
+    assert rel_err(y.detach().cpu(), yr.detach()) < 1e-4
+    (y * R.to(dev)).sum().backward()
+    want = dict(ref.named_parameters())
+    floor = 5e-2 * max(float(p.grad.abs().max()) for p in want.values())
+    for k, p in m.named_parameters():
+        assert torch.isfinite(p.grad).all(), k
+        assert grad_err(p.grad.cpu(), want[k].grad, floor) < 1e-3, k
+
+
+@pytest.mark.parametrize("B,T,Cc", [(1, 1, 3), (2, 5, 70), (3, 40, 64), (2, 100, 130)])
+def test_depthwise_conv_kernels_vs_torch(B, T, Cc):
+    """asr_dwconv (forward, data gradient = flipped taps) and asr_dwconv_bwd_w + asr_colsum against
+    torch.nn.functional.conv1d(groups = C, padding 15) in float64, including sequences shorter than the kernel."""
+    import ctypes as C
+    from asr_amd import _lib, ops
+    lib = _lib.load()
+    dev = _dev()
+    torch.manual_seed(B * 100 + T)
+    x, w, b, dy = torch.randn(B, T, Cc), torch.randn(Cc, 31), torch.randn(Cc), torch.randn(B, T, Cc)
+    xr, wr, br = (t.double().requires_grad_(True) for t in (x, w, b))
+    yr = torch.nn.functional.conv1d(xr.transpose(1, 2), wr.unsqueeze(1), br, padding=15, groups=Cc).transpose(1, 2)
+    yr.backward(dy.double())
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    xd, wd, bd, dyd = (t.to(dev).contiguous() for t in (x, w, b, dy))
+    y, dx = torch.empty_like(xd), torch.empty_like(xd)
+    _lib.check(lib.asr_dwconv(xd.data_ptr(), wd.data_ptr(), bd.data_ptr(), y.data_ptr(), B, T, Cc, 31, 0, st))
+    _lib.check(lib.asr_dwconv(dyd.data_ptr(), wd.data_ptr(), 0, dx.data_ptr(), B, T, Cc, 31, 1, st))
+    part = torch.empty(int(lib.asr_dwconv_bwd_w_chunks(B, T)), 31 * Cc, device=dev)
+    _lib.check(lib.asr_dwconv_bwd_w(dyd.data_ptr(), xd.data_ptr(), part.data_ptr(), B, T, Cc, 31, st))
+    dwkc = torch.empty(31, Cc, device=dev)
+    ops.colsum(part, dwkc.view(-1))
+    assert rel_err(y.cpu(), yr.detach()) < 1e-5
+    assert rel_err(dx.cpu(), xr.grad) < 1e-5
+    assert rel_err(dwkc.t().cpu(), wr.grad) < 1e-5
+    with pytest.raises(RuntimeError):
+        _lib.check(lib.asr_dwconv(xd.data_ptr(), wd.data_ptr(), bd.data_ptr(), y.data_ptr(), B, T, Cc, 15, 0, st))
