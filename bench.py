@@ -266,6 +266,11 @@ def main():
         # bucket's weight gradients (side stream) then holds back the next layer's recurrence behind
         # it (measured in a group of one: 37.8 -> 34.2 ms per step with this set)
         os.environ.setdefault("TORCH_NCCL_HIGH_PRIORITY", "1")
+        # RCCL prints a version banner on stdout when its first communicator comes up; stdout is reserved for the
+        # one JSON line, so file descriptor 1 points at stderr until the parameters have been broadcast
+        sys.stdout.flush()
+        saved_stdout = os.dup(1)
+        os.dup2(2, 1)
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
@@ -287,6 +292,11 @@ def main():
     log('model built')
     reducer = BucketedGradReducer(model, force=force_dp)
     reducer.broadcast_parameters()
+    if world > 1 or force_dp:
+        torch.cuda.synchronize()
+        sys.stdout.flush()
+        os.dup2(saved_stdout, 1)
+        os.close(saved_stdout)
     log('parameters broadcast')
     x, lengths, tgt, tl = make_batch(hp, dev, seed=1234 + rank)
     frames = make_batch.mel_frames
