@@ -84,12 +84,25 @@ def _linear(x2, W2, b=None, act=0):
     return y
 
 
-def _linear_bwd(dy2, x2, W2, bias=True, dx_out=None, accumulate=False, sums=None):
+def _zeros_like_all(*ws):
+    """One zero fill for several weight gradients (the split-K products add into them): views of one flat buffer."""
+    flat = torch.zeros(sum(w.numel() for w in ws), device=ws[0].device, dtype=torch.float32)
+    out, o = [], 0
+    for w in ws:
+        out.append(flat[o:o + w.numel()].view(w.shape))
+        o += w.numel()
+    return out
+
+
+def _linear_bwd(dy2, x2, W2, bias=True, dx_out=None, accumulate=False, sums=None, dW=None):
     """Returns (dx, dW, db) of y = x W^T + b; dx is written (or added) into dx_out when given.  With ``sums`` (a
     list) the bias gradient is only queued there as (dy2, db): the caller sums all of a block's bias gradients
     with one ops.colsum_multi call once the block's backward has produced them."""
-    dW = torch.empty_like(W2)
-    ops.matmul_tn(dy2, x2, dW)
+    if dW is None:
+        dW = torch.empty_like(W2)
+        ops.matmul_tn(dy2, x2, dW)
+    else:                                   # pre-zeroed by the caller (_zeros_like_all)
+        ops.matmul_tn(dy2, x2, dW, zeroed=True)
     db = None
     if bias:
         db = _e(W2.shape[0], like=x2)
@@ -165,12 +178,13 @@ class _FFFunction(torch.autograd.Function):
         p, m1, m_o, f = ctx.aux
         dy2 = dy.contiguous().view_as(x2)
         sums = []
+        zW1, zW2 = _zeros_like_all(w1, w2)
         do = _scale_mask(dy2, m_o, f)
-        ds, dW2, db2 = _linear_bwd(do, s, w2, sums=sums)
+        ds, dW2, db2 = _linear_bwd(do, s, w2, sums=sums, dW=zW2)
         da = torch.empty_like(a)
         check(lib.asr_swish_bwd(ds.data_ptr(), a.data_ptr(), m1.data_ptr() if m1 is not None else 0, da.data_ptr(),
                                 a.numel(), C.c_float(p if m1 is not None else 0.0), _st()))
-        dh, dW1, db1 = _linear_bwd(da, h, w1, sums=sums)
+        dh, dW1, db1 = _linear_bwd(da, h, w1, sums=sums, dW=zW1)
         ops.colsum_multi(sums)
         dx, dg, dbeta = _ln_bwd(dh, x2, ln_w, mean, rstd, dy2)
         return dx.view_as(dy), dg, dbeta, dW1, db1, dW2, db2, None, None, None, None
@@ -236,8 +250,9 @@ class _RelAttnFunction(torch.autograd.Function):
         proj, score, posp = (d, dk, T * d), (Tp, T * Tp, H * T * Tp), (d, dk, 0)
         dy2 = dy.contiguous().view_as(x2)
         sums = []
+        zWo, zWq, zWk, zWv, zWpos = _zeros_like_all(wo, wq, wk, wv, wpos)
         do = _scale_mask(dy2, m_o, f_o)
-        dcx, dWo, dbo = _linear_bwd(do, cx, wo, sums=sums)
+        dcx, dWo, dbo = _linear_bwd(do, cx, wo, sums=sums, dW=zWo)
         dattn = _e(B, H, T, Tp, like=x2)
         _head_gemm(dcx, vv, dattn, T, T, dk, H, B, a=proj, b=proj, c=score)                       # d attn = d ctx v^T
         dvv = torch.empty_like(vv)
@@ -259,12 +274,12 @@ class _RelAttnFunction(torch.autograd.Function):
         du, dv = _e(d, like=x2), _e(d, like=x2)
         sums += [(dqu, du), (dqv, dv)]
         dq = _axpby(dqu, dqv, 1.0, 1.0)
-        dh, dWq, dbq = _linear_bwd(dq, h, wq, sums=sums)
-        _, dWk, dbk = _linear_bwd(dkk, h, wk, dx_out=dh, accumulate=True, sums=sums)
-        _, dWv, dbv = _linear_bwd(dvv, h, wv, dx_out=dh, accumulate=True, sums=sums)
+        dh, dWq, dbq = _linear_bwd(dq, h, wq, sums=sums, dW=zWq)
+        _, dWk, dbk = _linear_bwd(dkk, h, wk, dx_out=dh, accumulate=True, sums=sums, dW=zWk)
+        _, dWv, dbv = _linear_bwd(dvv, h, wv, dx_out=dh, accumulate=True, sums=sums, dW=zWv)
         ops.colsum_multi(sums)                                              # six bias gradients, two launches
-        dWpos = torch.empty_like(wpos)
-        ops.matmul_tn(dpp, pe, dWpos)
+        dWpos = zWpos
+        ops.matmul_tn(dpp, pe, dWpos, zeroed=True)
         dx, dg, dbeta = _ln_bwd(dh, x2, nw, mean, rstd, dy2)
         return (dx.view_as(dy), dg, dbeta, dWq, dbq, dWk, dbk, dWv, dbv, dWpos, du.view(H, dk), dv.view(H, dk), dWo, dbo,
                 None, None, None, None, None)
@@ -318,8 +333,9 @@ class _ConvModuleFunction(torch.autograd.Function):
         W1, Wd, Wc, W2 = pw1w.view(2 * d, d), dww.view(d, KSIZE), cow.view(d, d), pw2w.view(d, d)
         dy2 = dy.contiguous().view_as(x2)
         bias_sums = []
+        zW1, zWc, zW2 = _zeros_like_all(W1, Wc, W2)
         do = _scale_mask(dy2, m_o, f_o)
-        ds, dW2, db2 = _linear_bwd(do, s, W2, sums=bias_sums)
+        ds, dW2, db2 = _linear_bwd(do, s, W2, sums=bias_sums, dW=zW2)
         part = _e(int(lib.asr_bn_blocks(rows)), 2 * d, like=x2)
         check(lib.asr_bn_swish_bwd_part(ds.data_ptr(), c2.data_ptr(), msum.data_ptr(), vsum.data_ptr(), C.c_float(ms),
                                         C.c_float(vs), bnw.data_ptr(), bnb.data_ptr(), part.data_ptr(), rows, d, LN_EPS, _st()))
@@ -329,7 +345,7 @@ class _ConvModuleFunction(torch.autograd.Function):
         check(lib.asr_bn_swish_bwd(ds.data_ptr(), c2.data_ptr(), msum.data_ptr(), vsum.data_ptr(), C.c_float(ms),
                                    C.c_float(vs), bnw.data_ptr(), bnb.data_ptr(), sums.data_ptr() if training else 0,
                                    dc2.data_ptr(), rows, d, LN_EPS, _st()))
-        dc1, dWc, dbc = _linear_bwd(dc2, c1, Wc, sums=bias_sums)
+        dc1, dWc, dbc = _linear_bwd(dc2, c1, Wc, sums=bias_sums, dW=zWc)
         ddb = _e(d, like=x2)
         bias_sums.append((dc1, ddb))
         wpart = _e(int(lib.asr_dwconv_bwd_w_chunks(B, T)), KSIZE * d, like=x2)
@@ -341,7 +357,7 @@ class _ConvModuleFunction(torch.autograd.Function):
         check(lib.asr_dwconv(dc1.data_ptr(), Wd.data_ptr(), 0, dg.data_ptr(), B, T, d, KSIZE, 1, _st()))
         da = torch.empty_like(a)
         check(lib.asr_glu_bwd(dg.data_ptr(), a.data_ptr(), da.data_ptr(), rows, d, _st()))
-        dh, dW1, db1 = _linear_bwd(da, h, W1, sums=bias_sums)
+        dh, dW1, db1 = _linear_bwd(da, h, W1, sums=bias_sums, dW=zW1)
         ops.colsum_multi(bias_sums)
         dx, dgam, dbeta = _ln_bwd(dh, x2, lnw, mean, rstd, dy2)
         return (dx.view_as(dy), dgam, dbeta, dW1.view_as(pw1w), db1, dWd.view_as(dww), ddb, dWc.view_as(cow), dbc,

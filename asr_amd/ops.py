@@ -116,7 +116,7 @@ def matmul_nn(x2d, W, out2d, accumulate=False):
           c_stride=out2d.stride(0), accumulate=accumulate)
 
 
-def matmul_tn(a2d, b2d, out2d):
+def matmul_tn(a2d, b2d, out2d, zeroed=False):
     """out (M,N) = a2d^T @ b2d with a2d (K,M), b2d (K,N) row-major (weight gradients).
 
     K is split over workgroups when M x N alone cannot fill the chip; out is
@@ -125,7 +125,7 @@ def matmul_tn(a2d, b2d, out2d):
     K, M = a2d.shape
     N = b2d.shape[1]
     sk = pick_splitk(M, N, K)
-    if sk > 1:
+    if sk > 1 and not zeroed:          # zeroed: the caller cleared out2d already (one fill for several gradients)
         out2d.zero_()
     sgemm(a2d, b2d, out2d, M, N, K, a_mode=1, a_stride=a2d.stride(0), b_mode=1, b_stride=b2d.stride(0),
           c_stride=out2d.stride(0), splitk=sk)
