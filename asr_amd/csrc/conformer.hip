@@ -72,30 +72,52 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float *__restrict__ d
         dg[i] = 0.f;
         db[i] = 0.f;
     }
-    for (int64_t r = r0 + w; r < min(rows, r0 + LN_BWD_ROWS); r += 4) {
-        const float mu = mean[r], rs = rstd[r];
-        float xh[NV], gy[NV];
-        float s1 = 0.f, s2 = 0.f;
+    // narrow rows (NV <= 4): the loads of all four rows of the wave are issued before the first reduction, so
+    // the row-to-row chain of load -> two wave reductions -> store does not expose one memory round trip per row
+    constexpr int RPW = NV <= 4 ? 4 : 1;
+    const int64_t rend = min(rows, r0 + LN_BWD_ROWS);
+    for (int64_t rb = r0 + w; rb < rend; rb += 4 * RPW) {
+        float dyv[RPW][NV], xv[RPW][NV], mus[RPW], rss[RPW];
 #pragma unroll
-        for (int i = 0; i < NV; ++i) {
-            const int c = lane + i * 64;
-            const float dyv = c < d ? dy[r * d + c] : 0.f;
-            xh[i] = c < d ? (x[r * d + c] - mu) * rs : 0.f;
-            gy[i] = dyv * gg[i];
-            dg[i] += dyv * xh[i];
-            db[i] += dyv;
-            s1 += gy[i];
-            s2 += gy[i] * xh[i];
+        for (int q = 0; q < RPW; ++q) {
+            const int64_t r = rb + 4 * q;
+            const bool ok = r < rend;
+            mus[q] = ok ? mean[r] : 0.f;
+            rss[q] = ok ? rstd[r] : 0.f;
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                const int c = lane + i * 64;
+                dyv[q][i] = (ok && c < d) ? dy[r * d + c] : 0.f;
+                xv[q][i] = (ok && c < d) ? x[r * d + c] : 0.f;
+            }
         }
-        s1 = wave_sum(s1) / d;
-        s2 = wave_sum(s2) / d;
 #pragma unroll
-        for (int i = 0; i < NV; ++i) {
-            const int c = lane + i * 64;
-            if (c < d) {
-                float v = rs * (gy[i] - s1 - xh[i] * s2);
-                if (res) v += res[r * d + c];
-                dx[r * d + c] = v;
+        for (int q = 0; q < RPW; ++q) {
+            const int64_t r = rb + 4 * q;
+            if (r >= rend) break;
+            const float mu = mus[q], rs = rss[q];
+            float xh[NV], gy[NV];
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                const int c = lane + i * 64;
+                xh[i] = c < d ? (xv[q][i] - mu) * rs : 0.f;
+                gy[i] = dyv[q][i] * gg[i];
+                dg[i] += dyv[q][i] * xh[i];
+                db[i] += dyv[q][i];
+                s1 += gy[i];
+                s2 += gy[i] * xh[i];
+            }
+            s1 = wave_sum(s1) / d;
+            s2 = wave_sum(s2) / d;
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                const int c = lane + i * 64;
+                if (c < d) {
+                    float v = rs * (gy[i] - s1 - xh[i] * s2);
+                    if (res) v += res[r * d + c];
+                    dx[r * d + c] = v;
+                }
             }
         }
     }
