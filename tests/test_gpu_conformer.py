@@ -298,3 +298,36 @@ def test_depthwise_conv_kernels_vs_torch(B, T, Cc):
     assert rel_err(dwkc.t().cpu(), wr.grad) < 1e-5
     with pytest.raises(RuntimeError):
         _lib.check(lib.asr_dwconv(xd.data_ptr(), wd.data_ptr(), bd.data_ptr(), y.data_ptr(), B, T, Cc, 15, 0, st))
+
+
+def test_eval_mode_backward_vs_oracle():
+    """Gradients in eval mode (BatchNorm normalises with its running statistics: the backward takes the branch
+    without the batch-statistics terms) against the CPU restatement."""
+    from oracle import ref_conformer as RC
+    z, meta = load_conf("conf_small")
+    dev = _dev()
+    ref = RC.TransformerEncoder(meta["idim"], meta["d_model"], meta["N_e"], meta["heads"], 0.0)
+    state = conf_state(z)
+    for k in state:                                   # non-trivial running statistics
+        if k.endswith("running_mean"):
+            state[k] = 0.3 * torch.randn_like(state[k])
+        if k.endswith("running_var"):
+            state[k] = 0.5 + torch.rand_like(state[k])
+    ref.load_state_dict(state)
+    m = _build(meta, state)
+    ref.eval()
+    m.eval()
+    src, src_pos = torch.from_numpy(z["src"]), torch.from_numpy(z["src_pos"])
+    R = torch.from_numpy(z["R"])
+    yr = ref(src, src_pos)
+    (yr * R).sum().backward()
+    y = m(src.to(dev), src_pos.to(dev))
+    assert rel_err(y.detach().cpu(), yr.detach()) < 1e-4
+    (y * R.to(dev)).sum().backward()
+    want = dict(ref.named_parameters())
+    floor = 5e-2 * max(float(p.grad.abs().max()) for p in want.values())
+    for k, p in m.named_parameters():
+        assert grad_err(p.grad.cpu(), want[k].grad, floor) < 1e-3, k
+    for k, v in m.state_dict().items():               # eval mode leaves the buffers alone
+        if "running_" in k:
+            assert torch.equal(v.cpu(), state[k]), k
