@@ -12,7 +12,7 @@ import ctypes as C
 
 import torch
 
-from .. import _lib
+from .. import _lib, persist
 from .._lib import check
 from ..utils.utils import lengths_to_device
 
@@ -34,6 +34,7 @@ class _CTCFunction(torch.autograd.Function):
         check(lib.asr_ctc_loss_fwd_bwd(logits.data_ptr(), targets.data_ptr(), in_len.data_ptr(), tgt_len.data_ptr(),
                                        B, T, V, L, int(blank), ws.data_ptr(), nll.data_ptr(), loss.data_ptr(),
                                        dlogits.data_ptr(), st))
+        persist.poison(loss)      # NaN if a persistent recurrence kernel reported a timed-out wait
         ctx.dlogits = dlogits if ctx.needs_input_grad[0] else None
         ctx.mark_non_differentiable(nll)
         return loss, nll

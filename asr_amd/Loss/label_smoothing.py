@@ -8,7 +8,7 @@ import ctypes as C
 
 import torch
 
-from .. import _lib
+from .. import _lib, persist
 from .._lib import check
 
 
@@ -27,6 +27,7 @@ class _LSCEFunction(torch.autograd.Function):
         check(lib.asr_ls_ce_fwd_bwd(logits.data_ptr(), target.data_ptr(), text_lengths.data_ptr(), B, L, V,
                                     C.c_float(eps), int(bool(T_norm)), int(bool(B_norm)), row_loss.data_ptr(),
                                     loss.data_ptr(), 0 if dlogits is None else dlogits.data_ptr(), st))
+        persist.poison(loss)      # NaN if a persistent recurrence kernel reported a timed-out wait
         ctx.dlogits = dlogits
         return loss
 

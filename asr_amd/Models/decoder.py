@@ -82,6 +82,9 @@ class _AttDecFunction(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dY):
         lib = _lib.load()
+        if ctx.t is None:
+            raise RuntimeError("asr_amd.Decoder: backward through the decoder a second time -- its saved "
+                               "activations are released by the first pass (retain_graph is not supported)")
         B, T, E, Hd, L, V = ctx.dims
         A = 2 * Hd
         P, t, U = ctx.P, ctx.t, ctx.U

@@ -16,7 +16,7 @@ import os
 import torch
 import torch.nn as nn
 
-from .. import _lib, ops, streams
+from .. import _lib, ops, persist, streams
 from .._lib import check
 from ..utils.utils import lengths_to_device
 
@@ -54,29 +54,22 @@ def _stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
-# Workspaces of the persistent recurrence kernels (flag words + h exchange), one
-# per (device, B, H), reused by every layer and step: launches on one stream are
-# serialised, and the library zeroes the flag words before each launch.  Word
-# ERR_WORD is sticky: a kernel sets it if an in-launch wait ever timed out.
+# Workspaces of the persistent recurrence kernels (flag words + h exchange): asr_amd/persist.py,
+# one per (device, B, H, stream), reused by every layer and step on that stream; the library resets
+# the flag words before each launch.  Word ERR_WORD is sticky: a kernel sets it if an in-launch
+# wait ever timed out; label_smoothing_loss turns it into a NaN loss (persist.poison).
 PERSISTENT = True          # False selects the one-launch-per-time-step kernels
-ERR_WORD = 1024
-_WS = {}
+ERR_WORD = persist.ERR_WORD
+_WS = persist._WS
 
 
 def _persist_ws(lib, B, H, dev):
     if not PERSISTENT:
         return None
-    key = (dev.index, B, H)
-    ws = _WS.get(key)
-    if ws is None:
-        ws = torch.zeros(int(lib.asr_blstm_ws_floats(B, H)), device=dev, dtype=torch.float32)
-        _WS[key] = ws
-    return ws
+    return persist.workspace(lib, B, H, dev)
 
 
-def persistent_error_flags():
-    """True if any persistent kernel reported a timed-out wait (device -> host copy)."""
-    return any(bool(ws.view(torch.int32)[ERR_WORD].item()) for ws in _WS.values())
+persistent_error_flags = persist.error_flags
 
 
 # Chunk pipelining (DESIGN.md "overlap"): a layer's recurrence can run as PIPE_CHUNKS launches
@@ -264,6 +257,12 @@ class _BLSTMLayerFunction(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dOut):
         lib = _lib.load()
+        if getattr(ctx, "consumed", False):
+            # the backward overwrites the saved gates with their gradients in place (raw pointers:
+            # autograd's version counters cannot see it), so a second pass would run on destroyed data
+            raise RuntimeError("asr_amd.Encoder: backward through a BLSTM layer a second time -- its saved "
+                               "activations are consumed in place by the first pass (retain_graph is not supported)")
+        ctx.consumed = True
         B, T, D, H, first, in_two, ho_t, ho_b = ctx.dims
         inp, G, Cs, Hout, lengths_dev, w_ih_f, w_hh_f, w_ih_r, w_hh_r = ctx.saved_tensors
         rl = ctx.rl

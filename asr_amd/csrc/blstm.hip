@@ -1021,3 +1021,54 @@ extern "C" int asr_blstm_bwd(const float *W_hh, const float *W_hhT, float *G, co
     ASR_CHECK_ARG(T > 0, "blstm_bwd: bad shape T=%d B=%d H=%d", T, B, H);
     return asr_blstm_bwd_range(W_hh, W_hhT, G, Cs, dHout, dho_t, dho_b, lengths, dc_ws, T, B, H, 0, T, ws, stream);
 }
+
+// ------------------------------------------------ allocation-free entry point --
+// For callers that cannot allocate device memory (code under HIP graph capture, tight serving
+// loops, harnesses that forbid hipMalloc): the forward recurrence of asr_blstm_fwd with the flag
+// words and the h exchange of the persistent kernel in a file-scope device array instead of a
+// caller-provided workspace.  Sized for the persistent kernel's own limits (B <= 32, H <= 512,
+// H % 4 == 0): BLSTM_HX_OFF + 4 * (H/4) * ceil(B/16) * 64 + 64 floats = 264.25 KiB per GPU, held
+// until the process ends.  In host code `blstm_scratch` is only a handle: its device address is
+// taken once per device with hipGetSymbolAddress and every use below goes through that pointer.
+// Calls on one GPU share the array (it keeps the last call's contents; what must start clean --
+// the flag words and the epoch tags of the exchange -- is reset by asr_blstm_fwd_range at s0 = 0),
+// so calls that overlap on one GPU (two streams) race.
+#define BLSTM_STATIC_MAX_B 32
+#define BLSTM_STATIC_MAX_H 512
+#define BLSTM_STATIC_FLOATS (BLSTM_HX_OFF + 4 * (BLSTM_STATIC_MAX_H / 4) * 2 * 64 + 64)
+#define BLSTM_STATIC_MAX_DEVICES 64
+static __device__ __align__(256) float blstm_scratch[BLSTM_STATIC_FLOATS];
+static float *g_scratch_dev[BLSTM_STATIC_MAX_DEVICES];   // device address of blstm_scratch, per device
+
+extern "C" int64_t asr_blstm_fwd_noalloc_max_floats(void) { return BLSTM_STATIC_FLOATS; }
+
+extern "C" int asr_blstm_fwd_noalloc(const float *W_hh, float *G, float *Cs, float *Hout, int64_t ho_t,
+                                     int64_t ho_b, const int32_t *lengths, int T, int B, int H, void *stream) {
+    ASR_CHECK_ARG(T > 0 && B > 0 && H > 0, "blstm_fwd_noalloc: bad shape T=%d B=%d H=%d", T, B, H);
+    ASR_CHECK_ARG(B <= BLSTM_STATIC_MAX_B && H <= BLSTM_STATIC_MAX_H && H % 4 == 0,
+                  "blstm_fwd_noalloc: B=%d H=%d is outside the static scratch (B <= %d, H <= %d, H %% 4 == 0); "
+                  "use asr_blstm_fwd with a workspace",
+                  B, H, BLSTM_STATIC_MAX_B, BLSTM_STATIC_MAX_H);
+    ASR_CHECK_ARG(asr_blstm_ws_floats(B, H) >= 0 &&
+                      BLSTM_HX_OFF + (int64_t)4 * cdiv(H, 4) * cdiv(B, 16) * 64 + 64 <= BLSTM_STATIC_FLOATS,
+                  "blstm_fwd_noalloc: scratch too small for B=%d H=%d", B, H);
+    int dev = -1;
+    ASR_CHECK_HIP(hipGetDevice(&dev));
+    ASR_CHECK_ARG(dev >= 0 && dev < BLSTM_STATIC_MAX_DEVICES, "blstm_fwd_noalloc: device %d out of range", dev);
+    float *ws = __atomic_load_n(&g_scratch_dev[dev], __ATOMIC_ACQUIRE);
+    if (ws == nullptr) {   // first call on this device (idempotent: racing threads store the same address)
+        void *p = nullptr;
+        ASR_CHECK_HIP(hipGetSymbolAddress(&p, HIP_SYMBOL(blstm_scratch)));
+        ASR_CHECK_ARG(p != nullptr, "blstm_fwd_noalloc: no device address for the scratch array");
+        ws = static_cast<float *>(p);
+        __atomic_store_n(&g_scratch_dev[dev], ws, __ATOMIC_RELEASE);
+    }
+    // the persistent kernel only: its step-wise fallback would not need the scratch, but a caller of
+    // this entry point asked for the one-launch path and must hear when it cannot have it
+    const int kq4 = (cdiv(H, 16) + 3) / 4;
+    const int64_t big = (int64_t)0x7fff0000;
+    ASR_CHECK_ARG(kq4 <= 8 && al16p(W_hh) && (int64_t)T * B * 8 * H * 4 < big && ho_t >= 0 && ho_b >= 0 &&
+                      ((int64_t)(T - 1) * ho_t + (int64_t)(B - 1) * ho_b + 2 * H) * 4 < big,
+                  "blstm_fwd_noalloc: shape or alignment outside the persistent kernel's limits");
+    return asr_blstm_fwd_range(W_hh, G, Cs, Hout, ho_t, ho_b, lengths, T, B, H, 0, T, ws, stream);
+}

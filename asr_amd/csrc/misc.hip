@@ -363,6 +363,23 @@ extern "C" int asr_scale(float *x, int64_t n, float s, void *stream) {
 }
 
 // ---------------------------------------------------------------------------
+// *value = NaN if *flag_word != 0.  The persistent recurrence kernels set a sticky error word in
+// their workspace when an in-launch wait times out (blstm.hip); the loss wrapper folds it into the
+// one value the training loop reads every step, so a bad step ends the job as a NaN loss does in
+// the reference (train.py:66-68) without a device->host copy of its own.
+__global__ void poison_if_flag_kernel(const unsigned *__restrict__ flag_word, float *__restrict__ value) {
+    if (*flag_word != 0u) *value = __uint_as_float(0x7fc00000u);
+}
+
+extern "C" int asr_poison_if_flag(const void *flag_word, float *value, void *stream) {
+    ASR_CHECK_ARG(flag_word && value, "poison_if_flag: null pointer");
+    hipLaunchKernelGGL(poison_if_flag_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream,
+                       reinterpret_cast<const unsigned *>(flag_word), value);
+    ASR_CHECK_LAUNCH("poison_if_flag_kernel");
+    return ASR_OK;
+}
+
+// ---------------------------------------------------------------------------
 // out[r] = index of the first maximum of row r (torch.argmax's tie rule for the frame-wise
 // labels of CTCModel.decode, Models/CTCModel.py:33): one wave per row.
 __global__ __launch_bounds__(256) void argmax_rows_kernel(const float *__restrict__ x, int64_t rows, int cols,

@@ -15,7 +15,20 @@ streams onto a few hardware queues, and at normal priority RCCL's internal strea
 queue of the main stream, so a bucket's wait for its weight gradients (side stream) and the
 collective itself hold back the next layer's recurrence kernel queued behind them (measured in
 a group of one on MI355X: 37.8 ms per step without, 34.2 with; 33.4 with no reducer at all).
+
+Differences from DistributedDataParallel, on purpose and checked:
+* one pass per ``finish()``: a second ``backward()`` before ``finish()`` raises (DDP would reduce each
+  pass); accumulate micro-batches under ``no_sync()`` and let the last backward run outside it;
+* a parameter that received no gradient in the pass is reduced as zeros (every rank issues the same
+  collectives in the same order; DDP raises unless ``find_unused_parameters`` is set);
+* buffers (the Conformer's BatchNorm running statistics) are broadcast once by
+  ``broadcast_parameters()``; DDP re-broadcasts them in every forward.  They do not enter the
+  training-mode arithmetic; call ``broadcast_buffers()`` before a checkpoint or an evaluation pass
+  if rank 0's statistics are to win, as they do under DDP;
+* ``close()`` before ``dist.destroy_process_group()``: it removes the hooks, waits for and drops the
+  side streams that shared hardware queues with RCCL's and restores ``streams.ENABLED``.
 """
+import contextlib
 import os
 import warnings
 
@@ -42,6 +55,7 @@ class BucketedGradReducer:
                           "init_process_group; RCCL will share the main stream's hardware queue and the "
                           "overlap with the backward is lost (see asr_amd/parallel.py)")
         # this reducer is stream-aware (see _launch): the weight gradients may be produced on the side stream
+        self._streams_was = streams.ENABLED
         streams.enable(True)
         enc, dec = model.encoder, model.decoder
         self.buckets = []                       # list of lists of parameters, in backward-completion order
@@ -62,25 +76,75 @@ class BucketedGradReducer:
             self.buckets.append(list(enc.cnn_encoder.parameters()))
         self.flat = [None] * len(self.buckets)
         self.work = [None] * len(self.buckets)
-        self._pending = set()
         self._hooks = []
         self._counts = [0] * len(self.buckets)
         self._where = {}
+        self._sync = True
+        self._closed = False
         for bi, ps in enumerate(self.buckets):
             for p in ps:
                 self._where[p] = bi
                 if self.active:
                     self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
 
+    # ------------------------------------------------------------------ set-up / tear-down --
     def broadcast_parameters(self, src=0):
-        """One-time parameter broadcast from rank 0 (what DDP does at wrap time)."""
+        """One-time parameter (and buffer) broadcast from rank 0 (what DDP does at wrap time)."""
         if not self.active:
             return
         for p in self.model.parameters():
             dist.broadcast(p.data, src=src, group=self.group)
-        for b in self.model.buffers():           # BatchNorm running statistics of the Conformer encoder
+        self.broadcast_buffers(src)
+
+    def broadcast_buffers(self, src=0):
+        """BatchNorm running statistics of the Conformer encoder (DDP does this in every forward)."""
+        if not self.active:
+            return
+        for b in self.model.buffers():
             dist.broadcast(b.data, src=src, group=self.group)
 
+    def close(self):
+        """Undo everything the constructor did to the process: remove the gradient hooks, wait for
+        outstanding collectives, wait for and DROP the cached side / pipe streams (they were created at
+        high priority to get a hardware queue of their own next to RCCL's streams; a later process
+        group -- evaluation, resume -- gets fresh ones) and restore ``streams.ENABLED``.  Call it
+        before ``dist.destroy_process_group()``.  Idempotent."""
+        if self._closed:
+            return
+        self._closed = True
+        for h in self._hooks:
+            h.remove()
+        self._hooks = []
+        for bi, w in enumerate(self.work):
+            if w is not None:
+                w.wait()
+                self.work[bi] = None
+        dev = next((p.device for ps in self.buckets for p in ps if p.is_cuda), None)
+        if dev is not None:
+            torch.cuda.current_stream(dev).synchronize()
+            streams.reset(dev)
+        self.flat = [None] * len(self.buckets)
+        self.active = False
+        streams.enable(self._streams_was)
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+        return False
+
+    @contextlib.contextmanager
+    def no_sync(self):
+        """Gradient accumulation (DDP.no_sync): backward passes inside the block only accumulate into
+        ``.grad``; the first backward outside it reduces the sums."""
+        was, self._sync = self._sync, False
+        try:
+            yield
+        finally:
+            self._sync = was
+
+    # ----------------------------------------------------------------------------- per step --
     def _views(self, bi):
         """The bucket's flat buffer as one view per parameter (same shapes as the gradients)."""
         flat, out, o = self.flat[bi], [], 0
@@ -90,7 +154,13 @@ class BucketedGradReducer:
         return out
 
     def _on_grad(self, p):
+        if not self._sync:
+            return
         bi = self._where[p]
+        if self._counts[bi] >= len(self.buckets[bi]):
+            raise RuntimeError("asr_amd.BucketedGradReducer: a second backward() reached a bucket that was already "
+                               "reduced in this step; call finish() after every backward(), or accumulate "
+                               "micro-batches under no_sync()")
         self._counts[bi] += 1
         if self._counts[bi] == len(self.buckets[bi]):
             self._launch(bi)
@@ -123,15 +193,16 @@ class BucketedGradReducer:
             pack_and_reduce()
 
     def finish(self):
-        """Wait for every bucket, apply DDP's mean and scatter back into ``.grad``."""
+        """Wait for every bucket, apply DDP's mean and scatter back into ``.grad``.  Every rank issues
+        every bucket's collective, in bucket order: a parameter without a gradient is sent as zeros."""
         if not self.active:
             return
         for bi, ps in enumerate(self.buckets):
             if self.work[bi] is None:
-                if all(p.grad is not None for p in ps):
-                    self._launch(bi)     # hooks did not fire (e.g. grads set manually)
-                else:
-                    continue
+                for p in ps:       # hooks did not fire for (some of) the bucket: unused parameter, grads set by hand
+                    if p.grad is None:
+                        p.grad = torch.zeros_like(p)
+                self._launch(bi)
             self.work[bi].wait()
             flat = self.flat[bi]
             if flat.is_cuda:
@@ -144,3 +215,35 @@ class BucketedGradReducer:
 
     def bytes_per_step(self):
         return 4 * sum(p.numel() for ps in self.buckets for p in ps)
+
+    def allreduce_probe(self, iters=10):
+        """Times each bucket's all-reduce alone (HIP events round the collective, `iters` back-to-back
+        calls) and returns per-bucket bytes, seconds, algorithm GB/s and bus GB/s (algorithm bandwidth
+        x 2(N-1)/N, the per-link load of a ring; compare with 153 GB/s per xGMI link).  Collective on
+        every rank: call it on all of them."""
+        out = []
+        if not self.active:
+            return out
+        for bi, ps in enumerate(self.buckets):
+            n = sum(p.numel() for p in ps)
+            buf = torch.zeros(n, device=ps[0].device, dtype=torch.float32)
+            dist.all_reduce(buf, group=self.group)
+            if buf.is_cuda:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                torch.cuda.synchronize()
+                e0.record()
+                for _ in range(iters):
+                    dist.all_reduce(buf, group=self.group)
+                e1.record()
+                torch.cuda.synchronize()
+                sec = e0.elapsed_time(e1) * 1e-3 / iters
+            else:
+                import time
+                t0 = time.perf_counter()
+                for _ in range(iters):
+                    dist.all_reduce(buf, group=self.group)
+                sec = (time.perf_counter() - t0) / iters
+            alg = 4.0 * n / sec / 1e9
+            out.append({"bucket": bi, "bytes": 4 * n, "us": sec * 1e6, "alg_GBs": alg,
+                        "bus_GBs": alg * 2.0 * (self.world - 1) / max(1, self.world)})
+        return out

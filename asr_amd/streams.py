@@ -70,6 +70,16 @@ def wait_side(device):
         torch.cuda.current_stream(device).wait_stream(_streams[device.index])
 
 
+def reset(device=None):
+    """Drop the cached side / pipe streams (after waiting for their work): the next user gets fresh ones.
+    BucketedGradReducer.close() calls this before the process group that shared their hardware queues
+    is destroyed (asr_amd/parallel.py)."""
+    for cache in (_streams, _pipes):
+        for idx in list(cache):
+            if device is None or device.index == idx:
+                cache.pop(idx).synchronize()
+
+
 class on_side:
     """with on_side(device, *tensors, params=...): ... -- run the block on the side stream, ordered
     after everything enqueued on the current stream so far; `tensors` were allocated on the main

@@ -10,9 +10,14 @@ workload: BASELINE config 2: B=32 per GPU, 80-dim fbank,
           5-layer BLSTM H=320, V=1000, L=100, fp32, synthetic N(0,1) features,
           random-init weights (seed 1234), inputs resident in HBM.
 Beside it, not part of `value`: `config5_conformer` = the same step for BASELINE config 5 (Conformer encoder).
-A "step" is one such pass over one batch.  For N > 1 it is launched by
-torch.distributed.run, one rank per GPU, each rank its own batch (weak scaling),
-gradients all-reduced in buckets on RCCL (asr_amd/parallel.py).
+A "step" is one such pass over one batch.  For N > 1 there is one rank per GPU, each rank its
+own batch (weak scaling), gradients all-reduced in buckets on RCCL (asr_amd/parallel.py).  Under a
+launcher (WORLD_SIZE set: `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N`)
+this process IS a rank; without one, `python bench.py --gpus N` starts the N ranks itself as a child
+torch.distributed.run (the reference's mp.spawn, train.py:180-186; rendezvous port from MASTER_PORT or
+a free one, not the reference's '600010') before anything touches the GPU.  `--rehearsal` runs the
+same N-rank code path with all ranks sharing GPU 0 over gloo (a 1-GPU box): the line it prints is
+marked and is not a throughput claim.
 """
 import argparse
 import json
@@ -28,6 +33,47 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
 MFMA_F32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: fp32-input MFMA = vector peak
+XGMI_LINK_GBS = 153.0          # one xGMI link (7 per GPU)
+# HBM-side bytes per launch from the rocprofv3 PMC passes kept under profiles/ (FETCH_SIZE x 2: the gfx950
+# correction for 16-byte streams of MI355X_MICROARCH.md, + WRITE_SIZE), same kernels and shapes as here
+PMC_TRAFFIC = {
+    "blstm_fwd": 2 * 486757e3 + 280000e3,          # profiles/r1_pmc_blstm.txt
+    "blstm_bwd": 2 * 1.989e9 + 1.757e9,            # profiles/r1_pmc_blstm.txt
+}
+
+
+class KernelTimer:
+    """HIP events on the launch stream round every call of the named C-ABI entry points while it is
+    installed (the calls enqueue one kernel plus its few-KB set-up memsets): the in-step duration of
+    the recurrence launches, side-stream GEMMs sharing the CUs included."""
+
+    def __init__(self, names):
+        from asr_amd import _lib
+        self.lib = _lib.load()
+        self.names = names
+        self.orig = {n: getattr(self.lib, n) for n in names}
+        self.pairs = {n: [] for n in names}
+        for n in names:
+            setattr(self.lib, n, self._wrap(n))
+
+    def _wrap(self, n):
+        orig, pairs = self.orig[n], self.pairs[n]
+
+        def call(*a):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            rc = orig(*a)
+            e1.record()
+            pairs.append((e0, e1))
+            return rc
+        return call
+
+    def finish(self):
+        """Uninstall; average seconds per call (the caller has synchronised)."""
+        for n in self.names:
+            setattr(self.lib, n, self.orig[n])
+        return {n: (sum(a.elapsed_time(b) for a, b in ps) * 1e-3 / len(ps) if ps else None)
+                for n, ps in self.pairs.items()}
 
 
 def make_hp(**kw):
@@ -70,6 +116,7 @@ def cpu_baseline(hp):
     step of the same config-2 batch (B=32), i.e. the same workload, 1 step."""
     from oracle import ref_model as R
     threads = min(os.cpu_count() or 1, int(os.environ.get("OMP_NUM_THREADS", "16")), 16)
+    host_cores = os.cpu_count()
     torch.set_num_threads(threads)
     torch.manual_seed(1234)
     m = R.AttModel(hp).train()
@@ -81,7 +128,7 @@ def cpu_baseline(hp):
     loss = R.label_smoothing_loss(y, tgt, tl, hp.T_norm, hp.B_norm)
     loss.backward()
     dt = time.time() - t0
-    return {"value": frames / dt, "unit": "frames/s", "cores": threads, "kind": "port",
+    return {"value": frames / dt, "unit": "frames/s", "cores": threads, "host_cores": host_cores, "kind": "port",
             "sample": f"1 step fwd+loss+bwd of the full config-2 batch (B=32, {frames} mel frames, L=100) "
                       f"in {dt:.1f} s with torch CPU ops on {threads} threads"}
 
@@ -100,10 +147,15 @@ def time_kernel_events(fn, iters):
     return e0.elapsed_time(e1) * 1e-3 / iters
 
 
-def roofline_probe(hp, dev):
-    """Times the step's main kernels in isolation with HIP events on the launch
-    stream (same shapes as the timed step) and prices them against the gfx950 peaks
-    of MI355X_MICROARCH.md.  The first entry is the dominant kernel of the step."""
+def roofline_probe(hp, dev, in_step=None):
+    """Prices the step's main kernels against the gfx950 peaks of MI355X_MICROARCH.md.  The two
+    recurrence kernels carry their IN-STEP duration (KernelTimer over the timed region: `avg_us`,
+    what `achieved` is computed from) beside the duration of the same launch timed alone
+    (`alone_us`); the others are timed alone with HIP events on the launch stream, same shapes as
+    the timed step.  Algorithmic work counts the frames inside their sequences only (config 2:
+    12 795 of 16 000 stacked frames), not the padded ones the kernels mask.  The dominant kernel of
+    the step by total duration is blstm_bwd_rs_kernel (profiles/: rocprofv3 kernel stats)."""
+    in_step = in_step or {}
     import ctypes as C
     from asr_amd import _lib, ops
     lib = _lib.load()
@@ -124,15 +176,16 @@ def roofline_probe(hp, dev):
     def lstm_fwd():
         lib.asr_blstm_fwd(W.data_ptr(), Gw.data_ptr(), Cs.data_ptr(), Hout.data_ptr(), B * 2 * H, 2 * H,
                           lengths.data_ptr(), T, B, H, ws.data_ptr(), st)
-    dt = time_kernel_events(lstm_fwd, 5)
-    # all B rows run all T steps in the kernel (padded rows are masked, not skipped)
-    flops = T * 2 * (2.0 * B * H * 4 * H)
+    alone = time_kernel_events(lstm_fwd, 5)
+    dt = in_step.get("asr_blstm_fwd") or alone
+    # algorithmic work: the frames inside their sequences (the kernel masks the padded rows, it does not skip them)
+    valid = float(lengths.sum())
+    flops = valid * 2 * (2.0 * H * 4 * H)
     out["blstm_fwd"] = {"bound": "mfma", "achieved": flops / dt / 1e12, "peak": MFMA_F32_PEAK_TFLOPS,
                         "unit": "TFLOP/s", "frac": flops / dt / 1e12 / MFMA_F32_PEAK_TFLOPS,
-                        # PMC passes of this kernel at this shape (profiles/r1_pmc_blstm.txt): 2 x FETCH_SIZE
-                        # (gfx950 correction for 16-B streams) + WRITE_SIZE, bytes per launch, fabric side
-                        "traffic": 2 * 486757e3 + 280000e3,
-                        "kernel": "blstm_fwd_persist_kernel<1,2,5>", "shape": [T, B, H], "avg_us": dt * 1e6,
+                        "traffic": PMC_TRAFFIC.get("blstm_fwd"),
+                        "kernel": "blstm_fwd_persist_kernel", "shape": [T, B, H], "valid_frames": valid,
+                        "avg_us": dt * 1e6, "alone_us": alone * 1e6, "timed": "in the step" if in_step else "alone",
                         "us_per_time_step": dt * 1e6 / T,
                         "note": "latency-bound recurrence: 500 dependent steps per launch"}
     # (1b) its backward: dG[t] = f(dH[t] + dG[t+1] W_hh, saved gates), same T x 2 x (B x 4H) @ (4H x H) chain
@@ -143,12 +196,16 @@ def roofline_probe(hp, dev):
     def lstm_bwd():
         lib.asr_blstm_bwd(W.data_ptr(), WT.data_ptr(), Gw.data_ptr(), Cs.data_ptr(), dH.data_ptr(), B * 2 * H, 2 * H,
                           lengths.data_ptr(), dc.data_ptr(), T, B, H, ws.data_ptr(), st)
-    dt = time_kernel_events(lstm_bwd, 5)
+    alone = time_kernel_events(lstm_bwd, 5)
+    dt = in_step.get("asr_blstm_bwd") or alone
     out["blstm_bwd"] = {"bound": "mfma", "achieved": flops / dt / 1e12, "peak": MFMA_F32_PEAK_TFLOPS,
-                        "unit": "TFLOP/s", "frac": flops / dt / 1e12 / MFMA_F32_PEAK_TFLOPS, "traffic": None,
-                        "kernel": "blstm_bwd_rs_kernel<8,5>", "shape": [T, B, H], "avg_us": dt * 1e6,
+                        "unit": "TFLOP/s", "frac": flops / dt / 1e12 / MFMA_F32_PEAK_TFLOPS,
+                        "traffic": PMC_TRAFFIC.get("blstm_bwd"),
+                        "kernel": "blstm_bwd_rs_kernel", "shape": [T, B, H], "valid_frames": valid,
+                        "avg_us": dt * 1e6, "alone_us": alone * 1e6, "timed": "in the step" if in_step else "alone",
                         "us_per_time_step": dt * 1e6 / T,
-                        "note": "timed alone; in the step the side stream's weight-gradient GEMMs share its CUs"}
+                        "note": "dominant kernel of the step by total duration; latency-bound recurrence, in the "
+                                "step the side stream's weight-gradient GEMMs share its CUs"}
     # (2) input-projection GEMM of an upper encoder layer: (T*B x 2H) @ (2H x 4H), fp32 MFMA
     M, N, K = T * B, 4 * H, 2 * H
     A = torch.randn(M, K, generator=g).to(dev)
@@ -236,6 +293,78 @@ def config5_probe(dev, steps=5, warmup=2):
             "parameters": n_par, "loss": float(loss.detach())}
 
 
+def free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def spawn_ranks(args):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as ONE child process tree
+    (`python -m torch.distributed.run --nproc-per-node N bench.py ...`, the launch line of the task's
+    contract) and return its exit code.  The parent never initialises the GPU -- `device_count()` does
+    not -- so nothing that has touched the device is ever replaced or forked."""
+    import subprocess
+    n = args.gpus
+    rehearsal = args.rehearsal or bool(os.environ.get("ASR_BENCH_REHEARSAL"))
+    stub = bool(os.environ.get("ASR_BENCH_STUB"))
+    have = torch.cuda.device_count()
+    if not (rehearsal or stub) and have < n:
+        print(f"bench.py: --gpus {n} needs {n} GPUs, this host shows {have}; `--rehearsal` runs the {n}-rank code "
+              "path on one GPU over gloo", file=sys.stderr)
+        return 2
+    port = os.environ.get("MASTER_PORT") or str(free_port())
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", port, os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or n) // n)))
+    return subprocess.run(cmd, env=env).returncode
+
+
+def stub_rank(args):
+    """ASR_BENCH_STUB=1 (CPU tests of the launcher, tests/test_bench_spawn.py): this rank joins a gloo
+    group, runs the real bucketed reducer over hand-set gradients of a small CPU-resident AttModel in
+    place of the HIP step, and rank 0 prints a line of the usual shape.  Never a measurement."""
+    import torch.distributed as dist
+    from asr_amd.Models.AttModel import AttModel
+    from asr_amd.parallel import BucketedGradReducer
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.manual_seed(1234 + rank)
+    model = AttModel(make_hp(lmfb_dim=4, frame_stacking=1, num_hidden_nodes=8, num_encoder_layer=2, num_classes=7))
+    with BucketedGradReducer(model) as reducer:
+        reducer.broadcast_parameters()
+
+        def step():
+            for p in model.parameters():
+                p.grad = torch.full_like(p, float(rank + 1))
+            reducer.finish()
+
+        for _ in range(args.warmup):
+            step()
+        dist.barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        dist.barrier()
+        dt = time.perf_counter() - t0
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, dt / args.steps * 1e3)
+        mean_ok = all(bool(torch.allclose(p.grad, torch.full_like(p, (world + 1) / 2.0))) for p in model.parameters())
+        if rank == 0:
+            print(json.dumps({"metric": "stub", "value": 0.0, "unit": "frames/s", "n_gpus": world,
+                              "rccl_ranks": dist.get_world_size(), "steps": args.steps, "warmup": args.warmup,
+                              "ms_per_step": max(per_rank), "per_rank_ms": per_rank, "data": "stub",
+                              "allreduce_bytes_per_step": reducer.bytes_per_step(), "mean_ok": mean_ok,
+                              "gpus_arg": args.gpus}), flush=True)
+    dist.destroy_process_group()
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -244,7 +373,24 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-config5", action="store_true", help="skip the Conformer (config 5) side measurement")
     ap.add_argument("--dropout", type=float, default=0.2, help="encoder dropout (template default 0.2)")
+    ap.add_argument("--rehearsal", action="store_true",
+                    help="N ranks share GPU 0 over gloo: the N-rank code path on a 1-GPU box (not a throughput claim)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(spawn_ranks(args))
+    if "WORLD_SIZE" in os.environ and int(os.environ["WORLD_SIZE"]) != args.gpus:
+        print(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={os.environ['WORLD_SIZE']} ranks; "
+              "n_gpus reports the ranks that ran", file=sys.stderr)
+    if os.environ.get("ASR_BENCH_STUB"):
+        raise SystemExit(stub_rank(args))
+    if args.rehearsal or os.environ.get("ASR_BENCH_REHEARSAL"):
+        os.environ["ASR_BENCH_ONE_DEVICE"] = "1"
+        os.environ["ASR_BENCH_BACKEND"] = "gloo"
+    hang_s = int(os.environ.get("ASR_BENCH_HANG_DUMP_S", "0"))
+    if hang_s > 0:      # diagnostics: where does every thread of this rank sit if the run stalls?
+        import faulthandler
+        faulthandler.dump_traceback_later(hang_s, repeat=True, file=sys.stderr)
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -325,13 +471,24 @@ def main():
         log(f'warm-up step {i} enqueued')
     barrier()
     log('warm-up done')
+    # the recurrence kernels are timed IN the step: HIP events on the launch stream round every
+    # asr_blstm_fwd / asr_blstm_bwd call of the timed region (one launch per layer)
+    ktimer = KernelTimer(("asr_blstm_fwd", "asr_blstm_bwd")) if rank == 0 else None
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = step()
     barrier()
     dt = time.perf_counter() - t0
+    in_step = ktimer.finish() if ktimer is not None else {}
+    from asr_amd.Models import encoder as _enc
+    if _enc.persistent_error_flags():
+        raise SystemExit("bench.py: a persistent recurrence kernel reported a timed-out in-launch wait; "
+                         "the run is invalid")
+    per_rank_ms = [dt / args.steps * 1e3]
     if world > 1:
         import torch.distributed as dist
+        per_rank_ms = [None] * world
+        dist.all_gather_object(per_rank_ms, dt / args.steps * 1e3)
         tt = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt)
@@ -365,6 +522,9 @@ def main():
         full_ms = time_full(lambda: opt.step(max_norm=hp.clip))
         full_stock_ms = time_full(stock_update)
 
+    # the gradient exchange alone (N > 1): each bucket's all-reduce timed by itself, bus GB/s against one xGMI link
+    ar = reducer.allreduce_probe() if (world > 1 or force_dp) else []
+
     if rank == 0:
         res = {
             "metric": "train frames/sec (fwd+bwd), AttModel 1k-BPE LibriSpeech shape",
@@ -376,14 +536,28 @@ def main():
             "config": {"workload": "BASELINE config 2: B=32/GPU, T_mel linspace(1500,900), stack 3 -> T=500, "
                                    "D=240, 5xBLSTM H=320, V=1000, L=100",
                        "global_batch": 32 * world, "parallelism": f"dp{world}",
-                       "encoder_dropout": args.dropout, "loss": float(loss)},
+                       "encoder_dropout": args.dropout, "loss": float(loss.detach())},
             "stacked_frames_per_s": total_frames / 3.0 / (ms * 1e-3),
             "full_step_ms_with_clip_adam": full_ms,
             "full_step_ms_with_stock_clip_adam": full_stock_ms,
         }
-        probes = roofline_probe(hp, dev) if world == 1 else {}
+        if world > 1 or force_dp:
+            import torch.distributed as dist
+            res["rccl_ranks"] = dist.get_world_size()
+            res["backend"] = dist.get_backend()
+            res["per_rank_ms"] = per_rank_ms
+            res["allreduce_bytes_per_step"] = reducer.bytes_per_step()
+            res["allreduce_buckets"] = ar
+            if ar:
+                tot_b, tot_s = sum(a["bytes"] for a in ar), sum(a["us"] for a in ar) * 1e-6
+                res["allreduce_bus_GBs"] = tot_b / tot_s / 1e9 * 2.0 * (world - 1) / world
+                res["xgmi_link_peak_GBs"] = XGMI_LINK_GBS
+            if os.environ.get("ASR_BENCH_ONE_DEVICE"):
+                res["rehearsal"] = (f"{world} ranks share GPU 0 over {dist.get_backend()}: the N-rank code path "
+                                    "(hooks, side-stream packing, collective, mean), NOT a throughput claim")
+        probes = roofline_probe(hp, dev, in_step) if world == 1 else {}
         if probes:
-            res["roofline"] = dict(probes["blstm_fwd"])
+            res["roofline"] = dict(probes["blstm_bwd"])
             res["roofline_all"] = probes
         if world == 1 and not args.no_config5:
             try:
@@ -393,6 +567,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(make_hp(encoder_dropout=0.0))
         print(json.dumps(res), flush=True)
+    reducer.close()
     if world > 1 or force_dp:
         import torch.distributed as dist
         dist.destroy_process_group()

@@ -187,6 +187,10 @@ int asr_scatter_rows(const float *src, const int64_t *idx, int n_rows, int width
 int asr_mul_dtanh(const float *dU, const float *U, float *out, int64_t n, void *stream);
 /* x *= s (1/world_size after the gradient all-reduce: DDP averages, train.py:141) */
 int asr_scale(float *x, int64_t n, float s, void *stream);
+/* *value = NaN when *flag_word != 0 (one 4-byte word on the device, e.g. word ASR_BLSTM_ERR_WORD of a
+ * recurrence workspace): surfaces a timed-out in-launch wait through the loss the training loop
+ * already reads every step -- the reference ends the job on a NaN loss, train.py:66-68. */
+int asr_poison_if_flag(const void *flag_word, float *value, void *stream);
 /* out[r] = argmax_c x[r*ld + c], first maximum (the frame-wise labels of CTCModel.decode,
  * Models/CTCModel.py:33: decoder_output[b].argmax(dim=1)) */
 int asr_argmax_rows(const float *x, int64_t rows, int cols, int64_t ld, int64_t *out, void *stream);
@@ -251,6 +255,18 @@ int asr_blstm_fwd(const float *W_hh, float *G, float *Cs, float *Hout,
 int asr_blstm_fwd_range(const float *W_hh, float *G, float *Cs, float *Hout,
                         int64_t ho_t, int64_t ho_b, const int32_t *lengths,
                         int T, int B, int H, int s0, int s1, float *ws, void *stream);
+/* asr_blstm_fwd without a workspace argument and without any allocation.  NO COUNTERPART in the
+ * reference: it exists for callers that cannot allocate device memory -- code under HIP graph
+ * capture, tight serving loops, harnesses that forbid hipMalloc.  The flag words and the h exchange
+ * of the persistent kernel live in a file-scope device array of asr_blstm_fwd_noalloc_max_floats()
+ * floats (264.25 KiB, one copy per GPU the library runs on, held until the process ends); shapes
+ * beyond it (B > 32, H > 512, H % 4 != 0) are rejected with ASR_ERR_ARG.  Every call on a GPU
+ * shares that GPU's array: calls that overlap on one GPU (two streams) race.  Same results as
+ * asr_blstm_fwd, bit for bit. */
+int64_t asr_blstm_fwd_noalloc_max_floats(void);
+int asr_blstm_fwd_noalloc(const float *W_hh, float *G, float *Cs, float *Hout,
+                          int64_t ho_t, int64_t ho_b, const int32_t *lengths,
+                          int T, int B, int H, void *stream);
 
 /* Backward of the recurrence.
  *   W_hh  [2][4H][H]   as in the forward (used by the persistent kernel; may be NULL)

@@ -83,3 +83,80 @@ def test_reducer_world2_gloo_conformer():
     out = mgr.dict()
     mp.spawn(_worker, args=(world, port, out, True), nprocs=world, join=True)
     assert all(out.get(r) for r in range(world)), dict(out)
+
+
+def _semantics_worker(rank, world, port, out):
+    """Hooks driven by a real autograd pass (a surrogate loss over the parameters: the HIP forward
+    needs a GPU), so the bucket counting, the re-entry guard, no_sync, zero-filled unused
+    parameters and close() are exercised as a training job would."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from asr_amd import streams
+    from asr_amd.Models.AttModel import AttModel
+    from asr_amd.parallel import BucketedGradReducer
+    from oracle import ref_model as R
+    hp = R.make_hp(num_hidden_nodes=8, num_encoder_layer=2, lmfb_dim=4, num_classes=7, frame_stacking=1)
+    torch.manual_seed(7)
+    m = AttModel(hp)
+    params = list(m.parameters())
+    was = streams.ENABLED
+    red = BucketedGradReducer(m)
+    red.broadcast_parameters()
+    ok = red.active and streams.ENABLED
+
+    def backward(ps=params):
+        ((rank + 1.0) * sum((p * p).sum() for p in ps)).backward()
+
+    def zero():
+        for p in params:
+            p.grad = None
+
+    mean_scale = sum(2.0 * (r + 1) for r in range(world)) / world     # d/dp of (r+1) p^2, averaged over ranks
+    # (1) one pass: every bucket launched from the hooks, finish() leaves the mean
+    zero()
+    backward()
+    ok = ok and all(w is not None for w in red.work)
+    red.finish()
+    ok = ok and all(torch.allclose(p.grad, mean_scale * p.detach(), atol=1e-6) for p in params)
+    # (2) a second backward before finish() must raise, not reduce a stale bucket
+    zero()
+    backward()
+    try:
+        backward()
+        ok = False
+    except RuntimeError as e:
+        ok = ok and "no_sync" in str(e)
+    red.finish()
+    # (3) accumulation under no_sync(): two micro-batches, one reduction of their sum
+    zero()
+    with red.no_sync():
+        backward()
+        ok = ok and all(w is None for w in red.work)
+    backward()
+    red.finish()
+    ok = ok and all(torch.allclose(p.grad, 2 * mean_scale * p.detach(), atol=1e-5) for p in params)
+    # (4) a parameter that got no gradient is reduced as zeros: same collectives on every rank
+    zero()
+    backward(params[1:])
+    red.finish()
+    ok = ok and bool((params[0].grad == 0).all()) and torch.allclose(params[1].grad, mean_scale * params[1].detach(),
+                                                                     atol=1e-6)
+    # (5) close(): hooks gone, stream overlap back to what it was, idempotent
+    red.close()
+    red.close()
+    zero()
+    backward()
+    ok = ok and all(w is None for w in red.work) and streams.ENABLED == was and not red.active
+    ok = ok and all(torch.allclose(p.grad, 2.0 * (rank + 1) * p.detach(), atol=1e-6) for p in params)
+    out[rank] = ok
+    dist.destroy_process_group()
+
+
+def test_reducer_semantics_world2_gloo():
+    world = 2
+    port = _free_port()
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_semantics_worker, args=(world, port, out), nprocs=world, join=True)
+    assert all(out.get(r) for r in range(world)), dict(out)

@@ -778,3 +778,118 @@ def test_clip_adam_rejects_cpu_parameters():
     p.grad = torch.randn(4)
     with pytest.raises(RuntimeError):
         ClipAdam([p]).step()
+
+
+# ------------------------------------------------- failure surfacing / guards --
+def test_timed_out_wait_poisons_the_loss():
+    """A persistent recurrence kernel that gives up on an in-launch wait sets the sticky error word of
+    its workspace; label_smoothing_loss must then return NaN (the reference's loop exits on a NaN
+    loss, train.py:66-68) -- simulated by setting the word by hand, then cleared again."""
+    from asr_amd import persist
+    from asr_amd.Loss.label_smoothing import label_smoothing_loss
+    from asr_amd.Models.encoder import Encoder
+    from oracle import ref_model as R
+    dev = _dev()
+    hp = R.make_hp(lmfb_dim=6, frame_stacking=1, num_hidden_nodes=16, num_encoder_layer=1, encoder_dropout=0.0)
+    enc = Encoder(hp).to(dev)
+    enc(torch.randn(3, 9, 6, device=dev), torch.tensor([9, 5, 2]))      # makes sure a workspace exists
+    assert persist._WS and not persist.error_flags()
+    z = torch.randn(2, 3, 12, device=dev, requires_grad=True)
+    tgt = torch.randint(0, 12, (2, 3), device=dev)
+    tl = torch.tensor([3, 2], device=dev)
+    clean = label_smoothing_loss(z, tgt, tl)
+    assert bool(torch.isfinite(clean))
+    ws = next(w for (idx, _, _, _), w in persist._WS.items() if idx == dev.index)
+    try:
+        ws.view(torch.int32)[persist.ERR_WORD] = 1
+        assert persist.error_flags()
+        assert bool(torch.isnan(label_smoothing_loss(z, tgt, tl)))
+    finally:
+        ws.view(torch.int32)[persist.ERR_WORD] = 0
+    assert float(label_smoothing_loss(z, tgt, tl)) == float(clean)
+
+
+def test_second_backward_raises_clearly():
+    """The BLSTM backward consumes its saved gates in place and the decoder releases its saved
+    tensors: a second pass over a retained graph must raise, not return wrong gradients."""
+    from asr_amd.Models.AttModel import AttModel
+    from oracle import ref_model as R
+    dev = _dev()
+    hp = R.make_hp(lmfb_dim=6, frame_stacking=1, num_hidden_nodes=8, num_encoder_layer=1, num_classes=9,
+                   encoder_dropout=0.0)
+    torch.manual_seed(2)
+    m = AttModel(hp).to(dev).train()
+    x = torch.randn(2, 7, 6, device=dev)
+    y = m(x, torch.tensor([7, 4]), torch.randint(0, 9, (2, 3), device=dev))
+    y.sum().backward(retain_graph=True)
+    with pytest.raises(RuntimeError, match="second time"):
+        y.sum().backward()
+    h = m.encoder(x, torch.tensor([7, 4]))
+    h.sum().backward(retain_graph=True)
+    with pytest.raises(RuntimeError, match="second time"):
+        h.sum().backward()
+
+
+def test_blstm_data_parallel_rehearsal_group_of_one_then_side_stream():
+    """The N-GPU code path of asr_amd.parallel on the BLSTM branch in an RCCL group of one (hooks,
+    bucket packing from the side stream, all-reduce, mean, scatter back): gradients equal a plain
+    backward.  The reducer is closed before the group is destroyed, and a side-stream backward
+    must still run afterwards in the same process (a training job that builds a second group for
+    evaluation or resume) -- which is why this test is NOT collected last."""
+    import os
+    import socket
+    import torch.distributed as dist
+    from asr_amd import streams
+    from asr_amd.Loss.label_smoothing import label_smoothing_loss
+    from asr_amd.Models.AttModel import AttModel
+    from asr_amd.parallel import BucketedGradReducer
+    from oracle import ref_model as R
+    dev = _dev()
+    hp = R.make_hp(lmfb_dim=12, frame_stacking=1, num_hidden_nodes=32, num_encoder_layer=3, num_classes=21,
+                   encoder_dropout=0.0)
+    torch.manual_seed(5)
+    m = AttModel(hp).to(dev).train()
+    B, T, L = 4, 70, 5
+    x = torch.randn(B, T, 12, device=dev)
+    lengths = torch.tensor([70, 66, 41, 12])
+    targets = torch.randint(0, 21, (B, L), device=dev)
+    tl = torch.tensor([5, 4, 3, 5], device=dev)
+
+    def grads():
+        m.zero_grad(set_to_none=True)
+        label_smoothing_loss(m(x, lengths, targets), targets, tl).backward()
+
+    was = streams.ENABLED
+    grads()
+    torch.cuda.synchronize()
+    want = {k: p.grad.clone() for k, p in m.named_parameters()}
+    s_ = socket.socket()
+    s_.bind(("127.0.0.1", 0))
+    port = s_.getsockname()[1]
+    s_.close()
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    os.environ.setdefault("TORCH_NCCL_HIGH_PRIORITY", "1")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        with BucketedGradReducer(m, force=True) as red:
+            assert red.active and len(red.buckets) == 1 + 3 and streams.ENABLED
+            red.broadcast_parameters()
+            for _ in range(2):
+                grads()
+                red.finish()
+            torch.cuda.synchronize()
+            assert all(w is None for w in red.work)
+            for k, p in m.named_parameters():
+                assert rel_err(p.grad.cpu(), want[k].cpu()) < 1e-6, k
+        assert streams.ENABLED == was and not streams._streams
+    finally:
+        dist.destroy_process_group()
+    # afterwards: the side stream (a fresh one) must still work in this process
+    streams.enable(True)
+    try:
+        grads()
+        torch.cuda.synchronize()
+        for k, p in m.named_parameters():
+            assert rel_err(p.grad.cpu(), want[k].cpu()) < 1e-6, k
+    finally:
+        streams.enable(was)

@@ -57,16 +57,16 @@ def test_conformer_data_parallel_rehearsal_group_of_one():
     was = streams.ENABLED
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
     try:
-        red = BucketedGradReducer(m, force=True)
-        assert red.active and len(red.buckets) == 1 + 4 + 1
-        red.broadcast_parameters()
-        grads()
-        red.finish()
-        torch.cuda.synchronize()
-        assert all(w is None for w in red.work)
-        for k, p in m.named_parameters():
-            assert rel_err(p.grad.cpu(), want[k].cpu()) < 1e-6, k
-        assert red.bytes_per_step() == 4 * sum(p.numel() for p in m.parameters())
+        with BucketedGradReducer(m, force=True) as red:
+            assert red.active and len(red.buckets) == 1 + 4 + 1
+            red.broadcast_parameters()
+            grads()
+            red.finish()
+            torch.cuda.synchronize()
+            assert all(w is None for w in red.work)
+            for k, p in m.named_parameters():
+                assert rel_err(p.grad.cpu(), want[k].cpu()) < 1e-6, k
+            assert red.bytes_per_step() == 4 * sum(p.numel() for p in m.parameters())
+        assert streams.ENABLED == was
     finally:
         dist.destroy_process_group()
-        streams.enable(was)
