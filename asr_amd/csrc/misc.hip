@@ -416,3 +416,38 @@ extern "C" int asr_argmax_rows(const float *x, int64_t rows, int cols, int64_t l
     ASR_CHECK_LAUNCH("argmax_rows_kernel");
     return ASR_OK;
 }
+
+// ---------------------------------------------------------------------------
+// A HIP stream with a hardware queue of its own.  HIP multiplexes a process's streams onto
+// GPU_MAX_HW_QUEUES (4) hardware queues PER PRIORITY; the one exception is a stream created with a
+// compute-unit mask, which always gets a new queue.  asr_amd/streams.py runs the off-critical-path
+// work (weight-gradient GEMMs, bucket packing) on such a stream: a queue of its own at NORMAL
+// priority.  (Round 1 used a high-priority stream for the same purpose; a high-priority stream that
+// waits on an event of the normal-priority main stream can starve it -- tools/stall_probe.py.)
+// cu_mask: n_words x 32 bits, bit i = compute unit i enabled (NULL / 0 words: every CU).
+extern "C" int asr_stream_create(void **stream, const uint32_t *cu_mask, int n_words) {
+    ASR_CHECK_ARG(stream != nullptr && n_words >= 0 && n_words <= 32, "stream_create: bad argument");
+    uint32_t all[32];
+    if (cu_mask == nullptr || n_words == 0) {
+        int dev = 0, cus = 0;
+        ASR_CHECK_HIP(hipGetDevice(&dev));
+        ASR_CHECK_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+        n_words = (cus + 31) / 32;
+        ASR_CHECK_ARG(n_words >= 1 && n_words <= 32, "stream_create: %d compute units", cus);
+        for (int w = 0; w < n_words; ++w) {
+            const int left = cus - 32 * w;
+            all[w] = left >= 32 ? 0xffffffffu : ((1u << left) - 1u);
+        }
+        cu_mask = all;
+    }
+    hipStream_t st = nullptr;
+    ASR_CHECK_HIP(hipExtStreamCreateWithCUMask(&st, (uint32_t)n_words, cu_mask));
+    *stream = (void *)st;
+    return ASR_OK;
+}
+
+extern "C" int asr_stream_destroy(void *stream) {
+    ASR_CHECK_ARG(stream != nullptr, "stream_destroy: null stream");
+    ASR_CHECK_HIP(hipStreamDestroy((hipStream_t)stream));
+    return ASR_OK;
+}

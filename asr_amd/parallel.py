@@ -10,11 +10,17 @@ and each bucket is one flat fp32 buffer, so every all-reduce is a single large
 RCCL call (xGMI is point-to-point: few large messages beat many small ones).
 The 1/world_size of DDP's mean is applied with asr_scale when the bucket lands.
 
-Set ``TORCH_NCCL_HIGH_PRIORITY=1`` before ``init_process_group``: HIP multiplexes a process's
-streams onto a few hardware queues, and at normal priority RCCL's internal stream lands on the
-queue of the main stream, so a bucket's wait for its weight gradients (side stream) and the
-collective itself hold back the next layer's recurrence kernel queued behind them (measured in
-a group of one on MI355X: 37.8 ms per step without, 34.2 with; 33.4 with no reducer at all).
+Stream priorities: everything runs at NORMAL priority, and ``TORCH_NCCL_HIGH_PRIORITY`` must stay
+unset.  HIP multiplexes a process's streams onto four hardware queues per priority class; a
+high-priority stream whose next packet is a wait on an event of a normal-priority stream can keep
+that stream's queue from being served at all -- measured on MI355X / ROCm 7.2 as a step that never
+ends, twice: a priority -1 side stream created after RCCL's streams waiting on the main stream's
+recurrence (tools/stall_probe.py, "plain" order), and RCCL's high-priority stream waiting on a
+normal-priority side stream at the config-2 size (bench.py, ASR_BENCH_FORCE_DP=1).  With all streams
+normal the only thing to lose is the overlap, when the side stream has to share the main stream's
+queue: call ``asr_amd.streams.prepare(device)`` before ``dist.init_process_group`` so the helper
+streams own their queues before RCCL creates its streams (group of one on MI355X: 34.2 ms per step
+with the reducer, 33.6 without any).
 
 Differences from DistributedDataParallel, on purpose and checked:
 * one pass per ``finish()``: a second ``backward()`` before ``finish()`` raises (DDP would reduce each
@@ -25,8 +31,8 @@ Differences from DistributedDataParallel, on purpose and checked:
   ``broadcast_parameters()``; DDP re-broadcasts them in every forward.  They do not enter the
   training-mode arithmetic; call ``broadcast_buffers()`` before a checkpoint or an evaluation pass
   if rank 0's statistics are to win, as they do under DDP;
-* ``close()`` before ``dist.destroy_process_group()``: it removes the hooks, waits for and drops the
-  side streams that shared hardware queues with RCCL's and restores ``streams.ENABLED``.
+* ``close()`` before ``dist.destroy_process_group()``: it removes the hooks (they would fire into a
+  dead group), waits for the side streams and restores ``streams.ENABLED``.
 """
 import contextlib
 import os
@@ -41,6 +47,26 @@ from . import ops, streams
 CONFORMER_LAYERS_PER_BUCKET = 4
 
 
+class _HostStagedWork:
+    """gloo has no device transport: handed a device tensor it stages through pinned memory on pool
+    streams and worker threads of its own.  For the one-GPU rehearsal of the N-rank path (all ranks on
+    one device over gloo) the reducer does that staging itself, where it can be seen: the packed
+    bucket is copied to pinned host memory on the stream that packed it (asynchronous, event behind
+    it); ``wait()`` -- called from finish(), in bucket order on every rank -- waits for the event,
+    all-reduces the HOST tensor and copies the sums back on the current stream."""
+
+    def __init__(self, flat, host, group):
+        self.flat, self.host, self.group = flat, host, group
+        self.host.copy_(flat, non_blocking=True)
+        self.ev = torch.cuda.Event()
+        self.ev.record(torch.cuda.current_stream(flat.device))
+
+    def wait(self):
+        self.ev.synchronize()
+        dist.all_reduce(self.host, op=dist.ReduceOp.SUM, group=self.group)
+        self.flat.copy_(self.host, non_blocking=True)
+
+
 class BucketedGradReducer:
     def __init__(self, model, process_group=None, force=False):
         """force: run the bucket machinery (hooks, packing, collective, mean) even in a group of
@@ -50,10 +76,10 @@ class BucketedGradReducer:
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         self.active = self.world > 1 or (force and dist.is_initialized())
         if (self.active and dist.get_backend(process_group) == "nccl"
-                and os.environ.get("TORCH_NCCL_HIGH_PRIORITY", "0") not in ("1", "true", "True")):
-            warnings.warn("asr_amd.BucketedGradReducer: TORCH_NCCL_HIGH_PRIORITY=1 was not set before "
-                          "init_process_group; RCCL will share the main stream's hardware queue and the "
-                          "overlap with the backward is lost (see asr_amd/parallel.py)")
+                and os.environ.get("TORCH_NCCL_HIGH_PRIORITY", "0") in ("1", "true", "True")):
+            warnings.warn("asr_amd.BucketedGradReducer: TORCH_NCCL_HIGH_PRIORITY=1 is set; a high-priority RCCL "
+                          "stream that waits on this reducer's normal-priority streams can starve them and "
+                          "the step never ends (see asr_amd/parallel.py) -- unset it")
         # this reducer is stream-aware (see _launch): the weight gradients may be produced on the side stream
         self._streams_was = streams.ENABLED
         streams.enable(True)
@@ -75,7 +101,12 @@ class BucketedGradReducer:
                 self.buckets.append([p for layer in reversed(group) for p in layer.parameters()])
             self.buckets.append(list(enc.cnn_encoder.parameters()))
         self.flat = [None] * len(self.buckets)
+        self.host = [None] * len(self.buckets)
         self.work = [None] * len(self.buckets)
+        # gloo + device tensors: stage through pinned memory here (see _HostStagedWork);
+        # ASR_GLOO_DEVICE_TENSORS=1 hands gloo the device tensors instead (its own staging)
+        self._stage = (self.active and dist.get_backend(process_group) == "gloo"
+                       and os.environ.get("ASR_GLOO_DEVICE_TENSORS", "0") != "1")
         self._hooks = []
         self._counts = [0] * len(self.buckets)
         self._where = {}
@@ -93,7 +124,7 @@ class BucketedGradReducer:
         if not self.active:
             return
         for p in self.model.parameters():
-            dist.broadcast(p.data, src=src, group=self.group)
+            self._broadcast(p.data, src)
         self.broadcast_buffers(src)
 
     def broadcast_buffers(self, src=0):
@@ -101,14 +132,20 @@ class BucketedGradReducer:
         if not self.active:
             return
         for b in self.model.buffers():
-            dist.broadcast(b.data, src=src, group=self.group)
+            self._broadcast(b.data, src)
+
+    def _broadcast(self, t, src):
+        if self._stage and t.is_cuda:
+            h = t.cpu()
+            dist.broadcast(h, src=src, group=self.group)
+            t.copy_(h)
+        else:
+            dist.broadcast(t, src=src, group=self.group)
 
     def close(self):
         """Undo everything the constructor did to the process: remove the gradient hooks, wait for
-        outstanding collectives, wait for and DROP the cached side / pipe streams (they were created at
-        high priority to get a hardware queue of their own next to RCCL's streams; a later process
-        group -- evaluation, resume -- gets fresh ones) and restore ``streams.ENABLED``.  Call it
-        before ``dist.destroy_process_group()``.  Idempotent."""
+        outstanding collectives and for the side / pipe streams' work (streams.reset) and restore
+        ``streams.ENABLED``.  Call it before ``dist.destroy_process_group()``.  Idempotent."""
         if self._closed:
             return
         self._closed = True
@@ -124,6 +161,7 @@ class BucketedGradReducer:
             torch.cuda.current_stream(dev).synchronize()
             streams.reset(dev)
         self.flat = [None] * len(self.buckets)
+        self.host = [None] * len(self.buckets)
         self.active = False
         streams.enable(self._streams_was)
 
@@ -175,6 +213,11 @@ class BucketedGradReducer:
         def pack_and_reduce():
             # one multi-tensor copy per bucket, not one launch per parameter
             torch._foreach_copy_(self._views(bi), [p.grad for p in ps])
+            if self._stage and flat.is_cuda:
+                if self.host[bi] is None or self.host[bi].numel() != n:
+                    self.host[bi] = torch.empty(n, dtype=torch.float32, pin_memory=True)
+                self.work[bi] = _HostStagedWork(flat, self.host[bi], self.group)
+                return
             # async_op: RCCL runs on the process group's own stream, ordered after the kernels
             # enqueued so far on the CURRENT stream; the backward keeps issuing work meanwhile
             self.work[bi] = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
@@ -227,6 +270,8 @@ class BucketedGradReducer:
         for bi, ps in enumerate(self.buckets):
             n = sum(p.numel() for p in ps)
             buf = torch.zeros(n, device=ps[0].device, dtype=torch.float32)
+            if self._stage and buf.is_cuda:     # rehearsal over gloo: the wire time of the host tensors
+                buf = torch.zeros(n, dtype=torch.float32, pin_memory=True)
             dist.all_reduce(buf, group=self.group)
             if buf.is_cuda:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

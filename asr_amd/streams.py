@@ -26,22 +26,81 @@ def enable(flag=True):
     ENABLED = bool(flag) and not _FORCED_OFF
 
 
+# How the helper streams are made (ASR_SIDE_STREAM_KIND):
+#   "cumask" (default): a stream created with a compute-unit mask (asr_stream_create) -- HIP gives such
+#       a stream a hardware queue of its OWN, at normal priority.  ASR_SIDE_CU_MASK picks the CUs: "all"
+#       (default) or "hi:N" = the upper N compute units of every XCD (CU-mask bit i is compute unit i // 8
+#       of XCD i % 8 on MI355X), which keeps the weight-gradient GEMMs off N..31 only.
+#   "priority": torch.cuda.Stream(priority=-1), round 1's way to a queue of its own.  A high-priority
+#       stream that waits on an event of the normal-priority main stream can starve it: with the stream
+#       created after RCCL's, the main stream's recurrence kernel never ran (tools/stall_probe.py,
+#       "plain" order) -- kept for A/B runs only.
+#   "normal": torch.cuda.Stream() -- shares one of 4 normal-priority hardware queues (after RCCL has
+#       created its streams: the MAIN stream's; the overlap then disappears, 37.8 vs 35.4 ms per step).
+KIND = os.environ.get("ASR_SIDE_STREAM_KIND", "normal")
 _streams = {}
+_pipes = {}
+_owned = []        # raw handles of the cumask streams: they live as long as the process
+
+
+def _cu_mask_words():
+    spec = os.environ.get("ASR_SIDE_CU_MASK", "all")
+    if spec == "all":
+        return None
+    kind, n = spec.split(":")
+    n = int(n)
+    bits = 0
+    for cu in range(32):
+        on = cu >= 32 - n if kind == "hi" else cu < n
+        if on:
+            for xcd in range(8):
+                bits |= 1 << (cu * 8 + xcd)
+    return [(bits >> (32 * w)) & 0xffffffff for w in range(8)]
+
+
+def _make(device):
+    if KIND == "priority":
+        return torch.cuda.Stream(device=device, priority=-1)
+    if KIND == "normal":
+        return torch.cuda.Stream(device=device)
+    import ctypes as C
+    from . import _lib
+    lib = _lib.load()
+    words = _cu_mask_words()
+    handle = C.c_void_p()
+    for _ in range(int(os.environ.get("ASR_SIDE_SPACERS", "0")) if not _owned else 0):   # experiment: queue placement
+        spacer = C.c_void_p()
+        with torch.cuda.device(device):
+            _lib.check(lib.asr_stream_create(C.byref(spacer), None, 0))
+    with torch.cuda.device(device):
+        if words is None:
+            _lib.check(lib.asr_stream_create(C.byref(handle), None, 0))
+        else:
+            arr = (C.c_uint32 * len(words))(*words)
+            _lib.check(lib.asr_stream_create(C.byref(handle), C.cast(arr, C.c_void_p), len(words)))
+    _owned.append((device.index, handle.value))
+    return torch.cuda.ExternalStream(handle.value, device=device)
+
+
+def prepare(device):
+    """Create the helper streams NOW and push one trivial operation through each, so that they own
+    their hardware queues before anybody else's streams exist.  Call it before
+    ``dist.init_process_group``: HIP hands the first four streams of a priority class a hardware queue
+    each and lets later ones share the least-used queue -- after RCCL has created its streams that is
+    the main stream's, and work meant to overlap the backward then queues behind it (no error, no
+    deadlock: only the overlap is lost)."""
+    for s in (side_stream(device), pipe_stream(device)):
+        with torch.cuda.stream(s):
+            torch.zeros(1, device=device)
+        s.synchronize()
 
 
 def side_stream(device):
     s = _streams.get(device.index)
     if s is None:
-        # High priority on purpose: HIP multiplexes a process's streams onto few hardware queues, and
-        # once RCCL has created its (high-priority) streams a normal-priority stream created here
-        # lands on the SAME hardware queue as the main stream -- measured: the overlap vanishes
-        # (37.8 vs 35.4 ms per step).  A high-priority stream keeps a queue of its own.
-        s = torch.cuda.Stream(device=device, priority=-1)
+        s = _make(device)
         _streams[device.index] = s
     return s
-
-
-_pipes = {}
 
 
 def pipe_stream(device):
@@ -50,7 +109,7 @@ def pipe_stream(device):
     two kinds of work never queue behind each other."""
     s = _pipes.get(device.index)
     if s is None:
-        s = torch.cuda.Stream(device=device, priority=-1)
+        s = _make(device)
         _pipes[device.index] = s
     return s
 
@@ -71,13 +130,17 @@ def wait_side(device):
 
 
 def reset(device=None):
-    """Drop the cached side / pipe streams (after waiting for their work): the next user gets fresh ones.
-    BucketedGradReducer.close() calls this before the process group that shared their hardware queues
-    is destroyed (asr_amd/parallel.py)."""
+    """Wait for the helper streams' work.  Pool streams of the "priority" / "normal" kinds are then
+    dropped, so the next user draws fresh ones; a CU-masked stream owns its hardware queue, shares it
+    with nobody and is kept (destroying it would pull the handle from under the caching allocator,
+    which records an event on every stream a block was used on when the block is freed).
+    BucketedGradReducer.close() calls this before its process group is destroyed."""
     for cache in (_streams, _pipes):
         for idx in list(cache):
             if device is None or device.index == idx:
-                cache.pop(idx).synchronize()
+                cache[idx].synchronize()
+                if KIND != "cumask":
+                    cache.pop(idx)
 
 
 class on_side:

@@ -293,6 +293,24 @@ def config5_probe(dev, steps=5, warmup=2):
             "parameters": n_par, "loss": float(loss.detach())}
 
 
+def start_watchdog(rank, dev):
+    """Rehearsal diagnostics: every 20 s one line per rank saying whether the device still retires work
+    (stream queries never block), so a stalled run names the rank and the stream that sit still."""
+    import threading
+    main = torch.cuda.current_stream(dev)
+
+    def loop():
+        from asr_amd import streams
+        n = 0
+        while True:
+            time.sleep(20)
+            n += 1
+            side = streams._streams.get(dev.index)
+            print(f"[bench rank {rank}] watchdog {20 * n:4d} s: main stream idle={main.query()} "
+                  f"side stream idle={side.query() if side is not None else None}", file=sys.stderr, flush=True)
+    threading.Thread(target=loop, daemon=True).start()
+
+
 def free_port():
     import socket
     s = socket.socket()
@@ -402,16 +420,15 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     force_dp = bool(os.environ.get("ASR_BENCH_FORCE_DP"))   # rehearsal: the N-GPU code path in a group of one
+    from asr_amd import streams as _streams
+    _streams.prepare(dev)      # helper streams own their hardware queues before RCCL creates its streams
     if world > 1 or force_dp:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
         backend = os.environ.get("ASR_BENCH_BACKEND", "nccl")     # "gloo": rehearsal on a 1-GPU box
-        # RCCL's own streams at high priority: HIP multiplexes a process's streams onto few hardware
-        # queues, and a normal-priority RCCL stream shares the MAIN stream's queue -- its wait for a
-        # bucket's weight gradients (side stream) then holds back the next layer's recurrence behind
-        # it (measured in a group of one: 37.8 -> 34.2 ms per step with this set)
-        os.environ.setdefault("TORCH_NCCL_HIGH_PRIORITY", "1")
+        # every stream at normal priority (TORCH_NCCL_HIGH_PRIORITY unset): a high-priority RCCL stream
+        # that waits on a normal-priority stream's event starved it on this platform -- asr_amd/parallel.py
         # RCCL prints a version banner on stdout when its first communicator comes up; stdout is reserved for the
         # one JSON line, so file descriptor 1 points at stderr until the parameters have been broadcast
         sys.stdout.flush()
@@ -437,9 +454,14 @@ def main():
     model = AttModel(hp).to(dev).train()
     log('model built')
     reducer = BucketedGradReducer(model, force=force_dp)
+    if world > 1 and os.environ.get("ASR_BENCH_ONE_DEVICE"):
+        start_watchdog(rank, dev)
     reducer.broadcast_parameters()
     if world > 1 or force_dp:
         torch.cuda.synchronize()
+        log('broadcast synchronised')
+        if world > 1 and not os.environ.get("ASR_BENCH_NO_BARRIER"):
+            dist.barrier()      # no rank starts its steps while another still drains its parameter copies
         sys.stdout.flush()
         os.dup2(saved_stdout, 1)
         os.close(saved_stdout)

@@ -191,6 +191,12 @@ int asr_scale(float *x, int64_t n, float s, void *stream);
  * recurrence workspace): surfaces a timed-out in-launch wait through the loss the training loop
  * already reads every step -- the reference ends the job on a NaN loss, train.py:66-68. */
 int asr_poison_if_flag(const void *flag_word, float *value, void *stream);
+/* A HIP stream with a hardware queue of its own at normal priority (created with a compute-unit
+ * mask: bit i of cu_mask = compute unit i; NULL / 0 words = every CU), for the work that overlaps the
+ * backward's critical path -- the reference leaves stream handling to DDP's reducer (train.py:141).
+ * Destroy it with asr_stream_destroy once its work has completed. */
+int asr_stream_create(void **stream, const uint32_t *cu_mask, int n_words);
+int asr_stream_destroy(void *stream);
 /* out[r] = argmax_c x[r*ld + c], first maximum (the frame-wise labels of CTCModel.decode,
  * Models/CTCModel.py:33: decoder_output[b].argmax(dim=1)) */
 int asr_argmax_rows(const float *x, int64_t rows, int cols, int64_t ld, int64_t *out, void *stream);
