@@ -36,7 +36,6 @@ def make_case():
 def test_two_rank_gradients_equal_single_rank(tmp_path):
     from asr_amd.Loss.label_smoothing import label_smoothing_loss
     from asr_amd.Models.AttModel import AttModel
-    from tests._util import rel_err
     assert torch.cuda.is_available(), "GPU tests need a GPU"
     dev = torch.device("cuda:0")
     hp, state, x, lengths, targets, tl = make_case()
@@ -70,6 +69,10 @@ def test_two_rank_gradients_equal_single_rank(tmp_path):
     r0 = np.load(tmp_path / "rank0.npz")
     r1 = np.load(tmp_path / "rank1.npz")
     assert abs((float(r0["loss"]) + float(r1["loss"])) - float(loss.detach())) < 1e-5 * abs(float(loss.detach()))
+    # 1e-6 of the tensor's largest entry; a gradient that is (nearly) zero in exact arithmetic -- the bias in front
+    # of the energy's tanh sums to ~1e-7 by cancellation -- is judged against 1e-4 of the model's largest gradient
+    floor = 1e-4 * max(float(p.grad.abs().max()) for p in m.parameters())
     for k, p in m.named_parameters():
         assert np.array_equal(r0[k], r1[k]), k                       # every rank holds the same mean
-        assert rel_err(2.0 * torch.from_numpy(r0[k]), p.grad.cpu()) < 1e-6, k
+        err = float((2.0 * torch.from_numpy(r0[k]) - p.grad.cpu()).abs().max())
+        assert err < 1e-6 * max(float(p.grad.abs().max()), floor), (k, err)
