@@ -12,7 +12,9 @@ Activations stay (B, T, C) row-major; no CPU fallback.
 Not mirrored: the per-layer attention maps the reference collects and drops (``attns_enc``, :361-364).
 """
 import ctypes as C
+import functools
 import math
+import os
 
 import torch
 import torch.nn as nn
@@ -24,6 +26,22 @@ KSIZE = 31      # Transformer_encoder.py:215
 LN_EPS = 1e-5   # nn.LayerNorm / nn.BatchNorm1d defaults
 BN_MOMENTUM = 0.1
 
+
+# Arithmetic of this encoder's matrix products (ops.gemm_precision).  Exact fp32 products by default: with the
+# bf16x3 split the deepest gradients of the 16-layer stack (through LayerNorm, the softmax and BatchNorm) land at
+# up to 3e-3 of their tensor's largest entry against the fp32 path at the config-5 size (tools/prec_compare.py),
+# outside the 1e-3 bar the fixtures are held to; the BLSTM path stays well inside it and uses the library default.
+# ASR_CONFORMER_GEMM_PRECISION=bf16x3 opts in (config 5 then trains faster, at that looser agreement).
+GEMM_PRECISION = os.environ.get("ASR_CONFORMER_GEMM_PRECISION", "f32")
+
+
+def _exact(fn):
+    """Run a forward / backward of this file under GEMM_PRECISION."""
+    @functools.wraps(fn)
+    def wrapped(*a, **k):
+        with ops.gemm_precision(GEMM_PRECISION):
+            return fn(*a, **k)
+    return wrapped
 
 def _st():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
@@ -155,6 +173,7 @@ class _FFFunction(torch.autograd.Function):
     inside ConformerEncoderLayer :259,265; n = 1 for ff_1, 2 for ff_2 whose output passes dropout_2 too)."""
 
     @staticmethod
+    @_exact
     def forward(ctx, x, ln_w, ln_b, w1, b1, w2, b2, scale, p, training, n_out_drop):
         lib = _lib.load()
         x2 = _req(x).view(-1, x.shape[-1])
@@ -172,6 +191,7 @@ class _FFFunction(torch.autograd.Function):
         return y.view_as(x)
 
     @staticmethod
+    @_exact
     def backward(ctx, dy):
         lib = _lib.load()
         x2, ln_w, w1, w2, mean, rstd, h, a, s = ctx.saved_tensors
@@ -208,6 +228,7 @@ class _RelAttnFunction(torch.autograd.Function):
     RelativeMultiHeadAttention :76-137)."""
 
     @staticmethod
+    @_exact
     def forward(ctx, x, nw, nb_, wq, bq, wk, bk, wv, bv, wpos, u, v, wo, bo, pe, keep, H, p, training):
         lib = _lib.load()
         B, T, d = x.shape
@@ -241,6 +262,7 @@ class _RelAttnFunction(torch.autograd.Function):
         return y.view_as(x)
 
     @staticmethod
+    @_exact
     def backward(ctx, dy):
         lib = _lib.load()
         (x2, nw, wq, wk, wv, wpos, wo, pe, keep, mean, rstd, h, qu, qv, k, vv, pp, attn, attn_d, cx) = ctx.saved_tensors
@@ -291,6 +313,7 @@ class _ConvModuleFunction(torch.autograd.Function):
     ConformerEncoderLayer :264).  BatchNorm statistics cover all B*T frames, as in the reference."""
 
     @staticmethod
+    @_exact
     def forward(ctx, x, lnw, lnb, pw1w, pw1b, dww, dwb, cow, cob, bnw, bnb, pw2w, pw2b, run_mean, run_var, p, training):
         lib = _lib.load()
         B, T, d = x.shape
@@ -325,6 +348,7 @@ class _ConvModuleFunction(torch.autograd.Function):
         return y.view_as(x)
 
     @staticmethod
+    @_exact
     def backward(ctx, dy):
         lib = _lib.load()
         (x2, lnw, pw1w, dww, cow, bnw, bnb, pw2w, mean, rstd, h, a, g, c1, c2, msum, vsum, s) = ctx.saved_tensors
@@ -371,6 +395,7 @@ class _CnnEmbeddingFunction(torch.autograd.Function):
     weight is used as its (odim, F2, C) permutation.  No gradient w.r.t. the features (they are data)."""
 
     @staticmethod
+    @_exact
     def forward(ctx, src, w1, b1, w2, b2, wout):
         lib = _lib.load()
         B, T, F = src.shape
@@ -395,6 +420,7 @@ class _CnnEmbeddingFunction(torch.autograd.Function):
         return out.view(B, T2, -1)
 
     @staticmethod
+    @_exact
     def backward(ctx, dout):
         lib = _lib.load()
         col1, y1, col2, y2, w2p, woutp = ctx.saved_tensors
@@ -524,6 +550,7 @@ class RelativePositionalEncoder(nn.Module):
 
 class _Dropout(torch.autograd.Function):
     @staticmethod
+    @_exact
     def forward(ctx, x, p):
         y, mask = _drop(x.contiguous(), p, True, _seed(True, p))
         ctx.save_for_backward(mask)
@@ -531,6 +558,7 @@ class _Dropout(torch.autograd.Function):
         return y
 
     @staticmethod
+    @_exact
     def backward(ctx, dy):
         return _drop_bwd(dy.contiguous(), ctx.saved_tensors[0], ctx.p), None
 

@@ -82,6 +82,7 @@ SYMBOLS = {
     "asr_ls_ce_fwd_bwd": (C.c_int, [c_f, c_f, c_f, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int,
                                     c_f, c_f, c_f, c_f]),
     "asr_sgemm": (C.c_int, [C.POINTER(GemmDesc), c_f]),
+    "asr_gemm_precision": (C.c_int, [C.c_int]),
     "asr_colsum": (C.c_int, [c_f, C.c_int, C.c_int, c_i64, c_i64, C.c_int, c_f, C.c_int, c_f, c_f]),
     "asr_colsum_ws_floats": (c_i64, [C.c_int, C.c_int]),
     "asr_colsum_multi_ws_floats": (c_i64, [C.POINTER(ColsumList), C.c_int]),

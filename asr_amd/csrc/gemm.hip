@@ -14,8 +14,11 @@
 // float4 along whichever index is contiguous in memory, prefetched into
 // registers one k-tile ahead of the MFMAs.
 #include <stdlib.h>
+#include <string.h>
 
 #include "common.cuh"
+
+#define ASR_GEMM_PRECISION_DEFAULT 1
 
 // LDS row padding: the k-contiguous source (mode 0) is scattered into the k-major tile as
 // 4-byte writes, lane -> (row = lane/4, k-chunk = lane%4); a row stride = 2 mod 8 floats puts the
@@ -40,7 +43,9 @@ __device__ __forceinline__ int64_t view_rowoff(const OperandView &v, int i) {
 // Per-thread slots of a (R x GK) operand tile, R/64 float4s each.
 //   mode 0: element (r,k) at p[rowoff(r0+r) + k];   slot f -> r = f>>2, k4 = f&3   (row fixed per slot)
 //   mode 1: element (r,k) at p[rowoff(k) + r0+r];   slot f -> k = f/(R/4), r4 = f%(R/4)
-template <int R, int GK, int MODE, bool FAST, bool KLIST = false>
+//   PAIRK (mode 1 only, the bf16 kernels): slots 2q and 2q+1 of a thread hold the SAME four rows at k = 2p and
+//   2p + 1, so the thread can pack the k pair of each row into one 32-bit word of two bf16.
+template <int R, int GK, int MODE, bool FAST, bool KLIST = false, bool PAIRK = false>
 struct TileLoader {
     static constexpr int NS = R * GK / 1024;   // float4 slots per thread
     static constexpr int KQ = GK / 4;          // float4s per row (mode 0)
@@ -73,6 +78,11 @@ struct TileLoader {
                 base[i] = r < rmax ? v.p + view_rowoff(v, midx ? midx[r] : r) : nullptr;
                 rk[i] = (f % KQ) * 4;
                 rcol[i] = 0;
+            } else if (PAIRK) {
+                const int r = r0 + (tid % (R / 4)) * 4;
+                base[i] = r < rmax ? v.p + r : nullptr;
+                rk[i] = 2 * (tid / (R / 4) + (1024 / R) * (i >> 1)) + (i & 1);
+                rcol[i] = r;
             } else {
                 const int r = r0 + (f % (R / 4)) * 4;
                 base[i] = r < rmax ? v.p + r : nullptr;
@@ -156,6 +166,51 @@ __device__ __forceinline__ void store_tile(float (*lds)[R + GPAD(MODE)], const f
         } else {
             const int k = f / (R / 4), r = (f % (R / 4)) * 4;
             *reinterpret_cast<float4 *>(&lds[k][r]) = regs[i];
+        }
+    }
+}
+
+// Epilogue shared by the fp32 and the bf16 kernels (the C/D layout of a 32x32 MFMA does not depend on the
+// input type): col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
+template <int TM, int TN>
+__device__ __forceinline__ void gemm_epilogue(const asr_gemm_desc &d, float *C, f32x16 (&acc)[TM][TN], int m0, int n0,
+                                              int wm, int wn, int WM, int WN, int split) {
+    const int lane = threadIdx.x & 63;
+    const bool first = (split == 0);
+    OperandView vc{nullptr, 0, d.c_s0, d.c_s1, d.c_d};
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        int64_t coff[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            coff[r] = row < d.M ? view_rowoff(vc, d.m_idx ? d.m_idx[row] : row) : -1;
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int col = n0 + wn * WN + j * 32 + (lane & 31);
+            if (col >= d.N) continue;
+            float bias = 0.f;
+            if (first) {
+                const int bh = d.bias_d > 0 ? col / d.bias_d : 0, bl = col - bh * (d.bias_d > 0 ? d.bias_d : 0);
+                if (d.bias1) bias += d.bias1[bh * d.bias1_s1 + bl];
+                if (d.bias2) bias += d.bias2[bh * d.bias2_s1 + bl];
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                if (coff[r] < 0) continue;
+                float *dst = C + coff[r] + col;
+                float v = d.alpha * acc[i][j][r] + bias;
+                if (d.splitk > 1) {
+                    atomicAdd(dst, v);
+                } else {
+                    if (d.accumulate) v += *dst;
+                    if (d.act == 1) v = tanh_f(v);
+                    else if (d.act == 2) v = fmaxf(v, 0.f);
+                    if (d.c_keep) v = d.c_keep[(dst - d.C)] ? v * d.c_keep_scale : 0.f;   // nbatch == 1
+                    *dst = v;
+                }
+            }
         }
     }
 }
@@ -246,44 +301,193 @@ __global__ __launch_bounds__(256) void sgemm_kernel(asr_gemm_desc d, int vecA, i
         cur ^= 1;
     }
 
-    // epilogue: C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
-    const bool first = (split == 0);
-    OperandView vc{nullptr, 0, d.c_s0, d.c_s1, d.c_d};
+    gemm_epilogue<TM, TN>(d, C, acc, m0, n0, wm, wn, WM, WN, split);
+}
+
+
+// ===================================================================== bf16 ==
+// The same products on the bf16 matrix pipe (v_mfma_f32_32x32x16_bf16: 16x the fp32 MFMA rate), fp32
+// accumulate.  Every fp32 operand element x is split while it is staged into LDS,
+//     hi = bf16(x),  lo = bf16(x - hi)            (round to nearest even both times),
+// and NPROD = 3 products are accumulated per k-step:  a_lo b_hi + a_hi b_lo + a_hi b_hi  (the bf16x3 split:
+// what is dropped -- a_lo b_lo and the residuals past 16 mantissa bits -- is below 2^-16 of |a||b| per
+// product; measured against the fp32 MFMA kernel in tests/test_gpu_parity.py::test_sgemm_bf16x3).  NPROD = 1 keeps
+// a_hi b_hi only: plain bf16 inputs (8 mantissa bits), an opt-in mode with a tolerance of its own.
+// LDS holds k-PAIR-major tiles of 32-bit words, word[kp][m] = {bf16 x[m][2kp], bf16 x[m][2kp+1]}: one
+// ds_read_b32 per lane and word is conflict-free (lanes = consecutive m), a lane's fragment of a
+// 32x32x16 MFMA (row m, k = 8h .. 8h+7) is words kp = 4h .. 4h+3.  GK = 32 (two k-steps per tile).
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4g __attribute__((ext_vector_type(4)));
+#define BF_GK 32
+#define BF_KP (BF_GK / 2)
+
+__device__ __forceinline__ unsigned bf_pack(float a, float b) {
+    bf16x2 v = {(__bf16)a, (__bf16)b};      // v_cvt_pk_bf16_f32 (RNE; NaN stays NaN)
+    return __builtin_bit_cast(unsigned, v);
+}
+// hi word and lo word of a pair of fp32 values
+__device__ __forceinline__ void bf_split(float a, float b, unsigned &hi, unsigned &lo) {
+    hi = bf_pack(a, b);
+    lo = bf_pack(a - __uint_as_float(hi << 16), b - __uint_as_float(hi & 0xffff0000u));
+}
+
+template <int R, int MODE, int NPROD>
+__device__ __forceinline__ void store_tile_bf(unsigned (*hi)[R + GPAD(MODE)], unsigned (*lo)[R + GPAD(MODE)],
+                                              const float4 (&regs)[R * BF_GK / 1024]) {
+    const int tid = threadIdx.x;
+    constexpr int NS = R * BF_GK / 1024;
+    if (MODE == 0) {       // a slot = 4 consecutive k of one row: two words
 #pragma unroll
-    for (int i = 0; i < TM; ++i) {
-        int64_t coff[16];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-            coff[r] = row < d.M ? view_rowoff(vc, d.m_idx ? d.m_idx[row] : row) : -1;
+        for (int i = 0; i < NS; ++i) {
+            const int f = tid + 256 * i;
+            const int r = f / (BF_GK / 4), kp = (f % (BF_GK / 4)) * 2;
+            unsigned h0, l0, h1, l1;
+            bf_split(regs[i].x, regs[i].y, h0, l0);
+            bf_split(regs[i].z, regs[i].w, h1, l1);
+            hi[kp][r] = h0;
+            hi[kp + 1][r] = h1;
+            if (NPROD > 1) {
+                lo[kp][r] = l0;
+                lo[kp + 1][r] = l1;
+            }
         }
+    } else {               // PAIRK: slots 2q, 2q+1 = the same four rows at k = 2p, 2p+1: four words, one 16-byte store
 #pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int col = n0 + wn * WN + j * 32 + (lane & 31);
-            if (col >= d.N) continue;
-            float bias = 0.f;
-            if (first) {
-                const int bh = d.bias_d > 0 ? col / d.bias_d : 0, bl = col - bh * (d.bias_d > 0 ? d.bias_d : 0);
-                if (d.bias1) bias += d.bias1[bh * d.bias1_s1 + bl];
-                if (d.bias2) bias += d.bias2[bh * d.bias2_s1 + bl];
-            }
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                if (coff[r] < 0) continue;
-                float *dst = C + coff[r] + col;
-                float v = d.alpha * acc[i][j][r] + bias;
-                if (d.splitk > 1) {
-                    atomicAdd(dst, v);
-                } else {
-                    if (d.accumulate) v += *dst;
-                    if (d.act == 1) v = tanh_f(v);
-                    else if (d.act == 2) v = fmaxf(v, 0.f);
-                    if (d.c_keep) v = d.c_keep[(dst - d.C)] ? v * d.c_keep_scale : 0.f;   // nbatch == 1
-                    *dst = v;
-                }
-            }
+        for (int q = 0; q < NS / 2; ++q) {
+            const int p = tid / (R / 4) + (1024 / R) * q, r = (tid % (R / 4)) * 4;
+            unsigned h0, h1, h2, h3, l0, l1, l2, l3;
+            bf_split(regs[2 * q].x, regs[2 * q + 1].x, h0, l0);
+            bf_split(regs[2 * q].y, regs[2 * q + 1].y, h1, l1);
+            bf_split(regs[2 * q].z, regs[2 * q + 1].z, h2, l2);
+            bf_split(regs[2 * q].w, regs[2 * q + 1].w, h3, l3);
+            *reinterpret_cast<u32x4g *>(&hi[p][r]) = u32x4g{h0, h1, h2, h3};
+            if (NPROD > 1) *reinterpret_cast<u32x4g *>(&lo[p][r]) = u32x4g{l0, l1, l2, l3};
         }
     }
+}
+
+template <int BM, int BN, int AMODE, int BMODE, int NPROD, bool KLIST = false>
+__global__ __launch_bounds__(256) void sgemm_bf_kernel(asr_gemm_desc d, int ktiles_per_split) {
+    constexpr int GK = BF_GK;
+    constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
+    constexpr int LO = NPROD > 1 ? 2 : 1;     // the lo images only exist for the split
+    __shared__ __attribute__((aligned(16))) unsigned Ah[2][BF_KP][BM + GPAD(AMODE)];
+    __shared__ __attribute__((aligned(16))) unsigned Bh[2][BF_KP][BN + GPAD(BMODE)];
+    __shared__ __attribute__((aligned(16))) unsigned Al[LO][NPROD > 1 ? BF_KP : 1][BM + GPAD(AMODE)];
+    __shared__ __attribute__((aligned(16))) unsigned Bl[LO][NPROD > 1 ? BF_KP : 1][BN + GPAD(BMODE)];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int n0 = blockIdx.x * BN, m0 = blockIdx.y * BM;
+    const int batch = blockIdx.z / d.splitk, split = blockIdx.z % d.splitk;
+    const int bhi = d.batch_d > 0 ? batch / d.batch_d : 0, blo = batch - bhi * (d.batch_d > 0 ? d.batch_d : 0);
+    OperandView va{d.A + (int64_t)blo * d.batch_a + (int64_t)bhi * d.batch_a1, d.a_mode, d.a_s0, d.a_s1, d.a_d};
+    OperandView vb{d.B + (int64_t)blo * d.batch_b + (int64_t)bhi * d.batch_b1, d.b_mode, d.b_s0, d.b_s1, d.b_d};
+    float *C = d.C + (int64_t)blo * d.batch_c + (int64_t)bhi * d.batch_c1;
+
+    const int kbeg = split * ktiles_per_split * GK;
+    const int kend = min(d.K, kbeg + ktiles_per_split * GK);
+    const int nk = kend > kbeg ? (kend - kbeg + GK - 1) / GK : 0;
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    float4 ra[BM * GK / 1024], rb[BN * GK / 1024];
+    TileLoader<BM, GK, AMODE, true, KLIST, AMODE == 1> la;
+    TileLoader<BN, GK, BMODE, true, KLIST, BMODE == 1> lb;
+    const int32_t *kidx = d.k_idx;
+    const int klast = d.K - 1;
+    la.init(va, m0, d.M, AMODE == 0 ? d.m_idx : nullptr);
+    lb.init(vb, n0, d.N, nullptr);
+    if (nk > 0) {
+        la.init_klist(kidx, kbeg, klast);
+        lb.init_klist(kidx, kbeg, klast);
+        la.load(va, d.M, kbeg, kend, 1, ra, kidx, klast);
+        lb.load(vb, d.N, kbeg, kend, 1, rb, kidx, klast);
+        la.apply_mask(ra);
+        lb.apply_mask(rb);
+        store_tile_bf<BM, AMODE, NPROD>(Ah[0], Al[0], ra);
+        store_tile_bf<BN, BMODE, NPROD>(Bh[0], Bl[0], rb);
+    }
+    __syncthreads();
+
+    const int kh = lane >> 5, l31 = lane & 31;
+    int cur = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+        const bool more = kt + 1 < nk;
+        if (more) {
+            la.load(va, d.M, kbeg + (kt + 1) * GK, kend, 1, ra, kidx, klast);
+            lb.load(vb, d.N, kbeg + (kt + 1) * GK, kend, 1, rb, kidx, klast);
+        }
+        const int lcur = NPROD > 1 ? cur : 0;
+#pragma unroll
+        for (int ks = 0; ks < GK / 16; ++ks) {
+            u32x4g ah[TM], al[TM], bh[TN], bl[TN];
+            const int kp = ks * 8 + kh * 4;
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int c = wm * WM + i * 32 + l31;
+                ah[i] = u32x4g{Ah[cur][kp][c], Ah[cur][kp + 1][c], Ah[cur][kp + 2][c], Ah[cur][kp + 3][c]};
+                if (NPROD > 1) al[i] = u32x4g{Al[lcur][kp][c], Al[lcur][kp + 1][c], Al[lcur][kp + 2][c], Al[lcur][kp + 3][c]};
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int c = wn * WN + j * 32 + l31;
+                bh[j] = u32x4g{Bh[cur][kp][c], Bh[cur][kp + 1][c], Bh[cur][kp + 2][c], Bh[cur][kp + 3][c]};
+                if (NPROD > 1) bl[j] = u32x4g{Bl[lcur][kp][c], Bl[lcur][kp + 1][c], Bl[lcur][kp + 2][c], Bl[lcur][kp + 3][c]};
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    if (NPROD > 1) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, al[i]),
+                                                                            __builtin_bit_cast(bf16x8, bh[j]), acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ah[i]),
+                                                                            __builtin_bit_cast(bf16x8, bl[j]), acc[i][j], 0, 0, 0);
+                    }
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ah[i]),
+                                                                        __builtin_bit_cast(bf16x8, bh[j]), acc[i][j], 0, 0, 0);
+                }
+        }
+        if (more) {
+            __builtin_amdgcn_sched_barrier(0);   // keep the wait for the prefetched tile behind the MFMAs
+            la.apply_mask(ra);
+            lb.apply_mask(rb);
+            store_tile_bf<BM, AMODE, NPROD>(Ah[cur ^ 1], Al[NPROD > 1 ? cur ^ 1 : 0], ra);
+            store_tile_bf<BN, BMODE, NPROD>(Bh[cur ^ 1], Bl[NPROD > 1 ? cur ^ 1 : 0], rb);
+        }
+        __syncthreads();
+        cur ^= 1;
+    }
+    gemm_epilogue<TM, TN>(d, C, acc, m0, n0, wm, wn, WM, WN, split);
+}
+
+// 0: exact fp32 products (v_mfma_f32_32x32x2_f32); 1: bf16x3 split products; 2: plain bf16 products.
+static int g_gemm_precision = -1;
+static int gemm_precision() {
+    if (g_gemm_precision < 0) {
+        const char *e = getenv("ASR_GEMM_PRECISION");
+        int m = ASR_GEMM_PRECISION_DEFAULT;
+        if (e) {
+            if (!strcmp(e, "f32") || !strcmp(e, "0")) m = 0;
+            else if (!strcmp(e, "bf16x3") || !strcmp(e, "1")) m = 1;
+            else if (!strcmp(e, "bf16") || !strcmp(e, "2")) m = 2;
+        }
+        g_gemm_precision = m;
+    }
+    return g_gemm_precision;
+}
+extern "C" int asr_gemm_precision(int mode) {
+    const int old = gemm_precision();
+    if (mode >= 0 && mode <= 2) g_gemm_precision = mode;
+    return old;
 }
 
 static bool aligned16(const void *p) { return (((uintptr_t)p) & 15) == 0; }
@@ -342,6 +546,49 @@ extern "C" int asr_sgemm(const asr_gemm_desc *din, void *stream) {
 
     hipStream_t st = (hipStream_t)stream;
     const int sel = d.a_mode * 2 + d.b_mode;
+    // bf16 matrix pipe (precision modes 1 and 2): fast-path shapes only, K worth a tile
+    const int prec = gemm_precision();
+    if (prec != 0 && fast && d.K >= 32 && d.M >= 32 && d.N >= 32) {
+        const int kt = cdiv(d.K, BF_GK);
+        int sk = din->splitk > 0 ? din->splitk : 1;
+        if (sk > kt) sk = kt;
+        d.splitk = sk;
+        const int perb = cdiv(kt, sk);
+        const int64_t zb = (int64_t)d.nbatch * sk;
+        const int64_t t128 = (int64_t)cdiv(d.M, 128) * cdiv(d.N, 128) * zb, t12864 = (int64_t)cdiv(d.M, 128) * cdiv(d.N, 64) * zb;
+        static int bf_tile = -1;
+        if (bf_tile < 0) {
+            const char *e = getenv("ASR_GEMM_BF_TILE");
+            bf_tile = e ? atoi(e) : 0;
+        }
+        int shape = bf_tile ? bf_tile : (d.M >= 128 && d.N >= 128 && t128 >= 512 ? 1 : (d.M >= 128 && t12864 >= 384 ? 2 : 3));
+#define BF_LAUNCH(BM_, BN_, AM, BM2, NP, KL)                                                                    \
+    hipLaunchKernelGGL((sgemm_bf_kernel<BM_, BN_, AM, BM2, NP, KL>), grid, dim3(256), 0, st, d, perb)
+#define BF_MODES(BM_, BN_, NP)                                   \
+    switch (sel) {                                               \
+        case 0: BF_LAUNCH(BM_, BN_, 0, 0, NP, false); break;     \
+        case 1: BF_LAUNCH(BM_, BN_, 0, 1, NP, false); break;     \
+        case 2: BF_LAUNCH(BM_, BN_, 1, 0, NP, false); break;     \
+        default:                                                 \
+            if (d.k_idx) BF_LAUNCH(BM_, BN_, 1, 1, NP, true);    \
+            else BF_LAUNCH(BM_, BN_, 1, 1, NP, false);           \
+            break;                                               \
+    }
+#define BF_SHAPE(BM_, BN_)                                                                          \
+    {                                                                                               \
+        dim3 grid(cdiv(d.N, BN_), cdiv(d.M, BM_), (unsigned)zb);                                    \
+        ASR_CHECK_ARG(grid.y <= 65535 && grid.z <= 65535, "sgemm: grid too large");                 \
+        if (prec == 1) { BF_MODES(BM_, BN_, 3) } else { BF_MODES(BM_, BN_, 1) }                     \
+    }
+        if (shape == 1) BF_SHAPE(128, 128)
+        else if (shape == 2) BF_SHAPE(128, 64)
+        else BF_SHAPE(64, 64)
+#undef BF_SHAPE
+#undef BF_MODES
+#undef BF_LAUNCH
+        ASR_CHECK_LAUNCH("sgemm_bf_kernel");
+        return ASR_OK;
+    }
 #define LAUNCH(BM_, BN_, GK_, AM, BM2, F)                                                              \
     hipLaunchKernelGGL((sgemm_kernel<BM_, BN_, GK_, AM, BM2, F>), grid, dim3(256), 0, st, d, vecA, vecB, per)
 #define LAUNCH_KLIST(BM_, BN_, GK_, F)                                                                 \

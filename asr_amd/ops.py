@@ -80,6 +80,26 @@ def sgemm(A, B, Cm, M, N, K, *, a_mode=0, b_mode=0, a_stride=None, b_stride=None
     check(lib.asr_sgemm(C.byref(d), _stream()))
 
 
+GEMM_MODES = {"f32": 0, "bf16x3": 1, "bf16": 2}
+
+
+class gemm_precision:
+    """with gemm_precision("f32" | "bf16x3" | "bf16"): ... -- arithmetic of the asr_sgemm products enqueued inside
+    the block (include/asr_amd.h, asr_gemm_precision); the previous mode comes back on exit.  The mode is read on
+    the host when a product is enqueued, so the block may end before the products have run."""
+
+    def __init__(self, mode):
+        self.mode = GEMM_MODES[mode] if isinstance(mode, str) else int(mode)
+
+    def __enter__(self):
+        self.old = _lib.load().asr_gemm_precision(self.mode)
+        return self
+
+    def __exit__(self, *exc):
+        _lib.load().asr_gemm_precision(self.old)
+        return False
+
+
 def elem_delta(a, b):
     """Element distance from tensor a to tensor b (both fp32) if a two-level GEMM view can
     address them as one operand (16-byte aligned distance), else None."""

@@ -155,6 +155,16 @@ typedef struct {
 } asr_gemm_desc;
 
 int asr_sgemm(const asr_gemm_desc *d, void *stream);
+/* Arithmetic of asr_sgemm's products (the reference multiplies in fp32 everywhere, Models/encoder.py:25-26):
+ *   0  exact fp32 products on v_mfma_f32_32x32x2_f32 (bit for bit an fmaf chain);
+ *   1  bf16x3: every fp32 operand split into two bf16 (hi + lo), three products per term on the bf16 matrix
+ *      pipe, fp32 accumulate -- ~16 mantissa bits per product, inside the fp32 parity bar (1e-4 / 1e-3);
+ *   2  plain bf16 products (8 mantissa bits), fp32 accumulate: the opt-in reduced-precision path, with a
+ *      looser, stated tolerance (tests/test_gpu_parity.py::test_bf16_mode_tolerance).
+ * Returns the previous mode; a mode outside 0..2 only queries.  Start-up value: environment variable
+ * ASR_GEMM_PRECISION = f32 | bf16x3 | bf16 (default bf16x3).  Shapes outside the fast path (unaligned
+ * operands, K < 32) use mode 0 whatever the setting. */
+int asr_gemm_precision(int mode);
 
 /* small helpers used by the backward passes (bias gradients, layouts) */
 /* out[n] (+)= sum_m A[rowoff(m) + n]; accumulate != 0 keeps the old value.

@@ -17,3 +17,30 @@ def pytest_collection_modifyitems(config, items):
     # they are deselected by `-m "not gpu"`.  If somebody runs them without a
     # GPU, fail loudly rather than pass on a fallback.
     pass
+
+
+# asr_sgemm's arithmetic modes (include/asr_amd.h, asr_gemm_precision) with the agreement each is held to against
+# a float64 product, max |err| / max |want|: exact fp32 products; the bf16x3 split (the library default: ~16
+# mantissa bits per product); plain bf16 products (the opt-in reduced-precision path, 8 mantissa bits).
+GEMM_MODES = [("f32", 2e-6), ("bf16x3", 2e-5), ("bf16", 2e-2)]
+
+
+@pytest.fixture(params=GEMM_MODES, ids=[m for m, _ in GEMM_MODES])
+def gemm_mode(request):
+    from asr_amd import ops
+    name, tol = request.param
+    with ops.gemm_precision(name):
+        yield tol, name
+
+
+@pytest.fixture(autouse=True)
+def _default_gemm_precision(request):
+    """Every GPU test starts and ends in the library's start-up mode, whatever a test before it did."""
+    if "gpu" not in request.keywords:
+        yield
+        return
+    from asr_amd import _lib
+    lib = _lib.load()
+    start = lib.asr_gemm_precision(-1)
+    yield
+    lib.asr_gemm_precision(start)

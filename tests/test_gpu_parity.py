@@ -33,8 +33,9 @@ def _build(hp, state):
                                    (300, 260, 64), (1000, 384, 40), (2304, 1408, 50), (2304, 1408, 64),
                                    (11968, 256, 256)])
 @pytest.mark.parametrize("a_mode,b_mode", [(0, 0), (0, 1), (1, 0), (1, 1)])
-def test_sgemm_modes(M, N, K, a_mode, b_mode):
+def test_sgemm_modes(M, N, K, a_mode, b_mode, gemm_mode):
     from asr_amd import ops
+    tol, _ = gemm_mode
     dev = _dev()
     g = torch.Generator().manual_seed(M * 7 + N * 3 + K + a_mode * 2 + b_mode)
     A = torch.randn((M, K) if a_mode == 0 else (K, M), generator=g)
@@ -45,16 +46,16 @@ def test_sgemm_modes(M, N, K, a_mode, b_mode):
     out = torch.full((M, N), 7.0, device=dev)
     ops.sgemm(Ad, Bd, out, M, N, K, a_mode=a_mode, b_mode=b_mode, a_stride=A.shape[1], b_stride=Bm.shape[1],
               c_stride=N, bias1=bd)
-    assert rel_err(out.cpu(), want) < 2e-6
+    assert rel_err(out.cpu(), want) < tol
     # accumulate + split-K (atomic) variants
     out2 = torch.ones(M, N, device=dev)
     ops.sgemm(Ad, Bd, out2, M, N, K, a_mode=a_mode, b_mode=b_mode, a_stride=A.shape[1], b_stride=Bm.shape[1],
               c_stride=N, bias1=bd, accumulate=True)
-    assert rel_err(out2.cpu(), want + 1.0) < 2e-6
+    assert rel_err(out2.cpu(), want + 1.0) < tol
     out3 = torch.zeros(M, N, device=dev)
     ops.sgemm(Ad, Bd, out3, M, N, K, a_mode=a_mode, b_mode=b_mode, a_stride=A.shape[1], b_stride=Bm.shape[1],
               c_stride=N, bias1=bd, splitk=3)
-    assert rel_err(out3.cpu(), want) < 2e-6
+    assert rel_err(out3.cpu(), want) < tol
 
 
 def test_sgemm_two_level_and_batched():
@@ -82,10 +83,11 @@ def test_sgemm_two_level_and_batched():
 
 @pytest.mark.parametrize("R,N,K,keep", [(9, 5, 3, 0.6), (300, 130, 40, 0.8), (2000, 256, 64, 0.75),
                                         (17000, 1280, 240, 0.8), (40, 12, 8, 1.0)])
-def test_sgemm_row_lists(R, N, K, keep):
+def test_sgemm_row_lists(R, N, K, keep, gemm_mode):
     """m_idx / k_idx: the products over a list of rows equal the dense products over those rows,
     unlisted rows of C stay untouched (a ragged batch skipping its padded frames)."""
     from asr_amd import ops
+    tol, _ = gemm_mode
     dev = _dev()
     g = torch.Generator().manual_seed(R + N + K)
     rows = torch.nonzero(torch.rand(R, generator=g) < keep).flatten().to(torch.int32)
@@ -102,7 +104,7 @@ def test_sgemm_row_lists(R, N, K, keep):
         ops.sgemm(Xd, Wop, out, n, N, K, b_mode=b_mode, a_stride=K, b_stride=Wop.shape[1], c_stride=N, m_idx=idx)
         want = torch.full((R, N), 7.0, dtype=torch.float64)
         want[rows.long()] = X.double()[rows.long()] @ W.double().t()
-        assert rel_err(out.cpu(), want) < 2e-6
+        assert rel_err(out.cpu(), want) < tol
     # weight-gradient form: dW (N x K) = sum over listed rows of dY[r]^T X[r]
     dY = torch.randn(R, N, generator=g)
     dYd = dY.to(dev)
@@ -110,17 +112,18 @@ def test_sgemm_row_lists(R, N, K, keep):
     for sk in (1, 3):
         gW = torch.zeros(N, K, device=dev)
         ops.sgemm(dYd, Xd, gW, N, K, n, a_mode=1, a_stride=N, b_mode=1, b_stride=K, c_stride=K, splitk=sk, k_idx=idx)
-        assert rel_err(gW.cpu(), want) < 1e-5      # fp32 sums over up to 13 600 rows
+        assert rel_err(gW.cpu(), want) < 5 * tol  # fp32 sums over up to 13 600 rows
     with pytest.raises(RuntimeError):
         ops.sgemm(dYd, Xd, gW, N, K, n, a_mode=1, a_stride=N, b_mode=1, b_stride=K, c_stride=K, m_idx=idx)
     with pytest.raises(RuntimeError):
         ops.sgemm(Xd, Wd, out, n, N, K, a_stride=K, b_stride=K, c_stride=N, k_idx=idx)
 
 
-def test_sgemm_two_tensor_operand_and_fused_keep():
+def test_sgemm_two_tensor_operand_and_fused_keep(gemm_mode):
     """One launch over two separately allocated weight / bias tensors (two-level views), and the
     dropout-backward mask applied in the epilogue."""
     from asr_amd import ops
+    tol, _ = gemm_mode
     dev = _dev()
     g = torch.Generator().manual_seed(77)
     M, K, Nh = 300, 48, 64
@@ -137,7 +140,7 @@ def test_sgemm_two_tensor_operand_and_fused_keep():
               bias1=b1f, bias2=b2f, bias_two=(Nh, d1, d2))
     want = torch.cat([X.double() @ Wf.double().t() + bf1.double() + bf2.double(),
                       X.double() @ Wr.double().t() + br1.double() + br2.double()], 1)
-    assert rel_err(out.cpu(), want) < 2e-6
+    assert rel_err(out.cpu(), want) < tol
     # dX form: reduction over the rows of both weight tensors, mask in the epilogue
     dG = torch.randn(M, 2 * Nh, generator=g)
     keep = (torch.rand(M, K, generator=g) < 0.8).to(torch.uint8)
@@ -145,7 +148,7 @@ def test_sgemm_two_tensor_operand_and_fused_keep():
     ops.sgemm(dG.to(dev), Wfd, dX, M, K, 2 * Nh, a_stride=2 * Nh, b_mode=1, b_two=(Nh, K, dw), c_stride=K,
               keep=keep.to(dev), keep_scale=1.25)
     want = (dG.double() @ torch.cat([Wf, Wr], 0).double()) * keep.double() * 1.25
-    assert rel_err(dX.cpu(), want) < 2e-6
+    assert rel_err(dX.cpu(), want) < tol
     assert torch.equal(dX.cpu() == 0, keep == 0) or float((dX.cpu() == 0).sum()) >= float((keep == 0).sum())
     with pytest.raises(RuntimeError):
         ops.sgemm(dG.to(dev), Wfd, dX, M, K, 2 * Nh, a_stride=2 * Nh, b_mode=1, b_two=(Nh, K, dw), c_stride=K,
@@ -892,3 +895,49 @@ def test_blstm_data_parallel_rehearsal_group_of_one_then_side_stream():
             assert rel_err(p.grad.cpu(), want[k].cpu()) < 1e-6, k
     finally:
         streams.enable(was)
+
+
+# ------------------------------------------------------- GEMM arithmetic modes --
+@pytest.mark.parametrize("mode,loss_tol,out_tol,grad_tol", [("f32", 1e-4, 1e-4, 1e-3), ("bf16x3", 1e-4, 1e-4, 1e-3),
+                                                            ("bf16", 1e-3, 2e-2, 5e-2)])
+def test_attmodel_gemm_precision_modes(mode, loss_tol, out_tol, grad_tol):
+    """The whole AttModel step at production widths (5 x BLSTM 320, attention 640, V = 1000) against the float64
+    oracle in each arithmetic mode of the hoisted matrix products: exact fp32 and the bf16x3 split (the default)
+    are held to the north-star bar (loss / youtput 1e-4, gradients 1e-3); plain bf16 products -- the opt-in
+    reduced-precision path -- to its own, stated, looser one (loss 1e-3, youtput 2e-2, gradients 5e-2).
+    Gradients: max |err| over the tensor / max(|tensor|max, 1e-3 of the model's largest gradient entry): at random
+    initialisation the attention's own gradients are ~1e-8 of the largest, where fp32 itself has no digits left."""
+    from asr_amd import ops
+    from asr_amd.Loss.label_smoothing import label_smoothing_loss
+    from asr_amd.Models.AttModel import AttModel
+    from oracle import ref_model as R
+    dev = _dev()
+    hp = R.make_hp(lmfb_dim=80, frame_stacking=3, num_hidden_nodes=320, num_encoder_layer=5, num_classes=1000,
+                   encoder_dropout=0.0)
+    torch.manual_seed(31)
+    ref = R.AttModel(hp).double()
+    B, T, L = 6, 48, 9
+    lengths = torch.tensor([48, 48, 40, 33, 20, 7])
+    x = torch.randn(B, T, 240)
+    for b in range(B):
+        x[b, lengths[b]:] = 0
+    tgt = torch.randint(0, 1000, (B, L))
+    tl = torch.tensor([9, 7, 9, 4, 6, 2])
+    yr = ref(x.double(), lengths, tgt)
+    lr = R.label_smoothing_loss(yr, tgt, tl, hp.T_norm, hp.B_norm)
+    lr.backward()
+    m = AttModel(hp)
+    m.load_state_dict({k: v.float() for k, v in ref.state_dict().items()})
+    m = m.to(dev).train()
+    with ops.gemm_precision(mode):
+        y = m(x.to(dev), lengths, tgt.to(dev))
+        loss = label_smoothing_loss(y, tgt.to(dev), tl.to(dev), hp.T_norm, hp.B_norm)
+        loss.backward()
+    torch.cuda.synchronize()
+    assert abs(float(loss.detach()) - float(lr.detach())) < loss_tol * abs(float(lr.detach()))
+    assert rel_err(y.detach().cpu(), yr.detach()) < out_tol
+    want = dict(ref.named_parameters())
+    floor = 1e-3 * max(float(q.grad.abs().max()) for q in want.values())
+    for k, p in m.named_parameters():
+        err = float((p.grad.cpu().double() - want[k].grad).abs().max())
+        assert err < grad_tol * max(float(want[k].grad.abs().max()), floor), (k, err)

@@ -1,0 +1,47 @@
+"""Config 2 at full size (dropout off): the float64 CPU oracle (oracle/ref_model.py, ~1-2 min on the box's host
+cores) against the HIP path in GEMM modes 0 (exact fp32 products), 1 (bf16x3) and 2 (bf16): loss, youtput and every
+gradient, max |err| / max |reference| per tensor.  GPU box only."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from asr_amd import _lib
+from asr_amd.Loss.label_smoothing import label_smoothing_loss
+from asr_amd.Models.AttModel import AttModel
+from bench import make_batch, make_hp
+from oracle import ref_model as R
+
+lib = _lib.load()
+dev = torch.device("cuda:0")
+torch.set_num_threads(min(16, os.cpu_count() or 1))
+hp = make_hp(encoder_dropout=0.0)
+torch.manual_seed(1234)
+m = AttModel(hp)
+state = {k: v.clone() for k, v in m.state_dict().items()}
+x, lengths, tgt, tl = make_batch(hp, torch.device("cpu"))
+t0 = time.time()
+ref = R.AttModel(hp).double()
+ref.load_state_dict({k: v.double() for k, v in state.items()})
+yr = ref(x.double(), lengths, tgt)
+lr = R.label_smoothing_loss(yr, tgt, tl, hp.T_norm, hp.B_norm)
+lr.backward()
+print(f"float64 oracle step: {time.time() - t0:.1f} s, loss {float(lr):.8f}", flush=True)
+want = {k: p.grad for k, p in ref.named_parameters()}
+gmax = max(float(g.abs().max()) for g in want.values())
+m = m.to(dev).train()
+xd, td, tld = x.to(dev), tgt.to(dev), tl.to(dev)
+for mode, tag in ((0, "f32"), (1, "bf16x3"), (2, "bf16")):
+    lib.asr_gemm_precision(mode)
+    m.zero_grad(set_to_none=True)
+    y = m(xd, lengths, td)
+    loss = label_smoothing_loss(y, td, tld, hp.T_norm, hp.B_norm)
+    loss.backward()
+    torch.cuda.synchronize()
+    errs = {k: float((p.grad.cpu().double() - want[k]).abs().max()) / float(want[k].abs().max())
+            for k, p in m.named_parameters()}
+    worst = sorted(errs.items(), key=lambda kv: -kv[1])[:4]
+    yerr = float((y.detach().cpu().double() - yr.detach()).abs().max() / yr.detach().abs().max())
+    print(f"mode {tag}: loss rel err {abs(float(loss.detach()) - float(lr)) / abs(float(lr)):.2e}  youtput {yerr:.2e}  "
+          f"gradients: max over tensors {max(errs.values()):.2e}, median {sorted(errs.values())[len(errs) // 2]:.2e}; worst: "
+          + ", ".join(f"{k} {v:.1e} (|g|max {float(want[k].abs().max()):.1e})" for k, v in worst), flush=True)
+print(f"largest gradient entry of the model: {gmax:.3e}")
+lib.asr_gemm_precision(1)
