@@ -66,6 +66,10 @@ class _AttDecFunction(torch.autograd.Function):
                        S=S, C=Cst, alpha=alpha, sproj=sproj, g=g, gates=gates, Fc=Fc, ws=ws)
         _fill_fwd_args(a, (B, T, E, Hd, L, V), tensors)
         check(lib.asr_attdec_fwd(C.byref(a), _stream()))
+        # a timed-out in-launch wait of the persistent loop kernel turns the first context into NaN (-> youtput,
+        # loss): the training loop's own NaN check ends the job, as in the reference (train.py:66-68)
+        check(lib.asr_poison_if_flag(ws.data_ptr() + 4 * int(lib.asr_attdec_err_offset(B, T, E, Hd, L)),
+                                     g.data_ptr(), _stream()))
         # hoisted: U = tanh(L_gy g + L_sy s), youtput = L_yy U   (Models/decoder.py:55)
         U = torch.empty(L, B, Hd, **f32)
         ops.linear_nt(g.view(L * B, E), P["W_gy"], U.view(L * B, Hd), bias1=P["b_gy"])

@@ -119,6 +119,9 @@ SYMBOLS = {
     "asr_dropout_bwd": (C.c_int, [c_f, c_f, c_f, c_i64, C.c_float, c_f]),
     "asr_attdec_ws_floats": (c_i64, [C.c_int] * 5),
     "asr_attdec_fwd": (C.c_int, [C.POINTER(AttDecFwdArgs), c_f]),
+    "asr_attdec_persist": (C.c_int, [C.c_int]),
+    "asr_attdec_debug_stamps": (None, [c_f]),
+    "asr_attdec_err_offset": (c_i64, [C.c_int] * 5),
     "asr_attdec_greedy": (C.c_int, [C.POINTER(AttDecFwdArgs), c_f, c_f, c_f, c_f, c_f, c_f, c_f]),
     "asr_attdec_step_att": (C.c_int, [C.POINTER(AttDecFwdArgs), c_f, c_f]),
     "asr_attdec_step_cell": (C.c_int, [C.POINTER(AttDecFwdArgs), c_f]),

@@ -719,10 +719,413 @@ static size_t energy_bwd2_smem(int A) {
 
 static bool al16(const void *p) { return (((uintptr_t)p) & 15) == 0; }
 
+// ===================================================== persistent forward ==
+// The whole teacher-forced loop of Models/decoder.py:52-60 in ONE launch.  Workgroup (b, k) of the
+// grid B x ceil(T/64) -- one per compute unit, all resident -- owns 64 frames of utterance b for the
+// energies and one column chunk of the context; the M = 32 products of a step (cell input, state
+// projection) are 16 x 16 tile jobs dealt over the same workgroups.  Per label step the data flows
+//   sproj_s[b]  -> energy (b, k)      -> e[b, 64 frames]                      (edge E)
+//   e[b, :]     -> softmax + context  -> alpha_s[b], g_s[b, chunk k]          (edge G)
+//   g_s, S_s    -> cell job (4 units x 16 rows) -> S_{s+1}, C_{s+1}, gates_s  (edge S)
+//   S_{s+1}     -> state-projection job (16 a x 16 rows) -> sproj_{s+1}       (edge P)
+// through the saved-activation tensors themselves (one slab per step: nothing is overwritten inside
+// the launch; the energies use two parity slots).  Hand-off form (MI355X_MICROARCH.md, valid forms,
+// flag row): payload stores sc1 -> every storing wave s_waitcnt vmcnt(0) -> workgroup barrier -> one
+// lane stores the producer's flag = step + 1 (sc1); consumer: wave 0 polls the flags it needs with
+// sc1 loads (bounded: a poll that runs out sets *err and the workgroup leaves, the others then run
+// out the same way, so the grid always drains) -> workgroup barrier -> every load of handed-off
+// bytes is an sc1 load.  Nothing depends on dispatch order or placement; it needs all workgroups
+// resident, which the host guarantees by size (grid <= number of CUs, one 1024-thread workgroup
+// each).  alpha_{s-1} never leaves the workgroup: every workgroup of an utterance normalises the
+// utterance's energies itself and keeps the result in LDS for the next step's convolution.
+#define PD_THREADS (E2W * 64)
+#define PD_SPIN_LIMIT (1 << 22)
+#define PD_OOB 0x7ffffff0
+typedef unsigned int pd_u32x4 __attribute__((ext_vector_type(4)));
+
+struct PDParams {
+    asr_attdec_fwd_args a;
+    const float *tab;      // padded W_fe / w_ee tables (e2_prep_kernel)
+    float *ebuf;           // [2][B][T] energies, parity slots
+    unsigned *flags;       // F_e [B*NTILE] | F_g [B*NTILE] | F_S [NJ*MTB] | F_sp [NSP*MTB]
+    unsigned *err;         // sticky error word
+    int NTILE, EC, NJ, NSP, MTB, Tp;
+    unsigned long long *stamps;   // diagnostics only (asr_attdec_debug_stamps): [workgroup][step][PD_NSTAMP] 100 MHz clock
+};
+#define PD_NSTAMP 10
+#define PD_STAMP(i)                                                                                   \
+    do {                                                                                              \
+        if (p.stamps != nullptr && tid == 0)                                                          \
+            p.stamps[((int64_t)w * L + s) * PD_NSTAMP + (i)] = __builtin_amdgcn_s_memrealtime();      \
+    } while (0)
+
+__device__ __forceinline__ float4 pd_ld4_sc1(__amdgpu_buffer_rsrc_t r, int byte_off) {
+    pd_u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, 16 /* sc1 */);
+    return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+}
+__device__ __forceinline__ float pd_ld_sc1(const float *p) {
+    return __uint_as_float(__hip_atomic_load(reinterpret_cast<const unsigned *>(p), __ATOMIC_RELAXED,
+                                             __HIP_MEMORY_SCOPE_AGENT));
+}
+__device__ __forceinline__ void pd_st_sc1(float *p, float v) {
+    __hip_atomic_store(reinterpret_cast<unsigned *>(p), __float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// one wave: wait until flags[i * stride] >= want for i < n.  false on timeout.
+__device__ __forceinline__ bool pd_poll(const unsigned *flags, int n, int stride, unsigned want) {
+    const int lane = threadIdx.x & 63;
+    for (int spins = 0; spins < PD_SPIN_LIMIT; ++spins) {
+        bool ok = true;
+        for (int i = lane; i < n; i += 64)
+            ok = ok && __hip_atomic_load(flags + (int64_t)i * stride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= want;
+        if (__all(ok)) return true;
+        __builtin_amdgcn_s_sleep(1);
+    }
+    return false;
+}
+// 16 x 16 tile product with the A rows read through sc1 buffer loads (data another workgroup wrote
+// in this launch) and the B rows (weights) through plain loads; K % 4 == 0.  Same k split over waves
+// and lanes as tile16_seg.
+__device__ __forceinline__ void pd_tile16_seg(Tile16Acc &acc, __amdgpu_buffer_rsrc_t ra, int row_byte_off,
+                                              const float *wrow, int K, const float *safe) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    const int slots = nw * 4;
+    int kq = (K + slots - 1) / slots;
+    kq = (kq + 3) & ~3;
+    const int kb = (wave * 4 + (lane >> 4)) * kq;
+    const int ke = min(K, kb + kq);
+#pragma unroll 4
+    for (int u = 0; u < kq; u += 4) {
+        const int k = kb + u;
+        const float4 a = pd_ld4_sc1(ra, (row_byte_off >= 0 && k < ke) ? row_byte_off + 4 * k : PD_OOB);
+        const float4 b = t16_load_fast(wrow, k, ke, safe);
+        acc.a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b.x, acc.a0, 0, 0, 0);
+        acc.a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b.y, acc.a1, 0, 0, 0);
+        acc.a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b.z, acc.a0, 0, 0, 0);
+        acc.a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b.w, acc.a1, 0, 0, 0);
+    }
+}
+
+#define PD_WAIT(cond)                                                                                   \
+    do {                                                                                                \
+        if (wave == 0) {                                                                                \
+            if (!(cond) && lane == 0) {                                                                 \
+                *s_abort = 1;                                                                           \
+                __hip_atomic_store(p.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);              \
+            }                                                                                           \
+        }                                                                                               \
+        __syncthreads();                                                                                \
+        if (*s_abort) return;                                                                           \
+    } while (0)
+#define PD_PUBLISH(flagptr, val)                                                                        \
+    do {                                                                                                \
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                \
+        __syncthreads();                                                                                \
+        if (tid == 0) __hip_atomic_store((flagptr), (unsigned)(val), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); \
+    } while (0)
+
+static size_t attdec_persist_smem(int A, int T) {
+    const int A16 = (A + 15) & ~15, Tp = (T + 3) & ~3;
+    return sizeof(float) * (size_t)(A16 * 14 + TT * 12 + ((TT + KW + 3) & ~3) + NCH * KW + E2P * 64 + 2 * Tp + 4096 +
+                                    T16_MAXW * 16 * 17 + 64);
+}
+
+__global__ __launch_bounds__(PD_THREADS) void attdec_fwd_persist_kernel(PDParams p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const asr_attdec_fwd_args &a = p.a;
+    const int B = a.B, T = a.T, E = a.E, Hd = a.Hd, L = a.L, V = a.V, A = 2 * Hd;
+    const int NTILE = p.NTILE, MTB = p.MTB, NJ = p.NJ, NSP = p.NSP, EC = p.EC;
+    const int w = blockIdx.x, nWG = gridDim.x;
+    const int b = w / NTILE, k = w - b * NTILE, t0 = k * TT;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int len = min(a.lengths[b], T);
+    const int A16 = round16(A);
+    E2Smem m;
+    m.sp = smem;
+    m.wfe = m.sp + A16;
+    m.wee = m.wfe + A16 * 12;
+    m.Fs = m.wee + A16;               // [TT][12]
+    m.aw = m.Fs + TT * 12;            // [TT + KW]
+    m.cw = m.aw + round4(TT + KW);    // [NCH*KW]
+    m.red = m.cw + NCH * KW;          // [E2P][64]
+    float *al = m.red + E2P * 64;     // [2][Tp] alpha of the previous / current step
+    float *cred = al + 2 * p.Tp;      // [1024 / (EC/4)][EC] context partial sums
+    float (*red16)[16][17] = reinterpret_cast<float (*)[16][17]>(cred + 4096);
+    float *sred = cred + 4096 + T16_MAXW * 16 * 17;     // [32]
+    int *s_abort = reinterpret_cast<int *>(sred + 32);
+
+    unsigned *F_e = p.flags, *F_g = F_e + B * NTILE, *F_S = F_g + B * NTILE, *F_sp = F_S + NJ * MTB;
+    const int64_t BH = (int64_t)B * Hd, BT = (int64_t)B * T, BA = (int64_t)B * A, BE = (int64_t)B * E;
+    __amdgpu_buffer_rsrc_t rS = __builtin_amdgcn_make_buffer_rsrc(a.S, 0, (int)((L + 1) * BH * 4), 0x00020000);
+    __amdgpu_buffer_rsrc_t rG = __builtin_amdgcn_make_buffer_rsrc(a.g, 0, (int)(L * BE * 4), 0x00020000);
+    __amdgpu_buffer_rsrc_t rP = __builtin_amdgcn_make_buffer_rsrc(a.sproj, 0, (int)(L * BA * 4), 0x00020000);
+
+    // tables that stay in LDS for all L steps
+    for (int i = tid; i < A16 * 13; i += PD_THREADS) m.wfe[i] = p.tab[i];
+    for (int i = tid; i < NCH * KW; i += PD_THREADS) m.cw[i] = a.conv_w[i];
+    for (int i = tid; i < A16; i += PD_THREADS) m.sp[i] = 0.f;
+    if (tid == 0) *s_abort = 0;
+    __syncthreads();
+
+    // energy roles (as energy_fwd2_kernel)
+    const int q = lane >> 4, col = lane & 15;
+    const int tt = wave & 3, part = wave >> 2;
+    const int tl = 16 * tt + col;
+    const int nrows = max(0, min(TT, len - t0));
+    const bool rowok = tl < nrows;
+    const float *PHrow = a.PH + ((int64_t)b * T + t0 + tl) * A;
+    const int MT = A16 / 16, MTP = (MT + E2P - 1) / E2P;
+    const int mt0 = part * MTP, mt1 = min(MT, mt0 + MTP);
+    const int nact = (len + TT - 1) / TT;       // tiles of this utterance that hold frames
+    const float *hb = a.hbatch + (int64_t)b * T * E;
+
+    for (int s = 0; s < L; ++s) {
+        float *al_cur = al + (s & 1) * p.Tp;
+        const float *al_prev = al + ((s & 1) ^ 1) * p.Tp;
+        float *eb = p.ebuf + (int64_t)(s & 1) * BT + (int64_t)b * T;
+        PD_STAMP(0);
+        // ---- A. this utterance's state projection (edge P)
+        if (s > 0) {
+            PD_WAIT(pd_poll(F_sp + b / 16, NSP, MTB, (unsigned)s));
+            if (4 * tid < A) {
+                const float4 v = pd_ld4_sc1(rP, (int)((((int64_t)s * B + b) * A + 4 * tid) * 4));
+                *reinterpret_cast<float4 *>(m.sp + 4 * tid) = v;
+            }
+        }
+        PD_STAMP(1);
+        // ---- B. energies of this workgroup's 64 frames
+        float *Fout = a.Fc + (((int64_t)s * B + b) * T + t0) * NCH;
+        if (nrows > 0) {
+            float4 ph[E2PF];
+#pragma unroll
+            for (int jx = 0; jx < E2PF; ++jx)
+                ph[jx] = e2_load_ph(PHrow, rowok && mt0 + jx < mt1, 16 * (mt0 + jx) + 4 * q, A, a.PH);
+            if (s > 0) {
+                for (int i = tid; i < TT + KW; i += PD_THREADS) {
+                    const int t = t0 - PADW + i;
+                    m.aw[i] = (t >= 0 && t < T) ? al_prev[t] : 0.f;
+                }
+            }
+            __syncthreads();
+            if (wave < 4) {
+                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+                if (s > 0) {
+                    const float *arow = m.aw + 16 * wave + col + q;
+                    const float *brow = m.cw + (col < NCH ? col : 0) * KW + q;
+#pragma unroll 5
+                    for (int ks = 0; ks < KW / 4; ++ks) {
+                        const float bv = col < NCH ? brow[4 * ks] : 0.f;
+                        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(arow[4 * ks], bv, acc, 0, 0, 0);
+                    }
+                }
+                if (col < 12) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) m.Fs[(16 * wave + 4 * q + r) * 12 + col] = acc[r];
+                }
+            }
+            __syncthreads();
+            {
+                const int n = min(TT, T - t0) * NCH;
+                for (int i = tid; i < n; i += PD_THREADS) Fout[i] = m.Fs[(i / NCH) * 12 + (i % NCH)];
+            }
+            float fB[3];
+#pragma unroll
+            for (int ks = 0; ks < 3; ++ks) fB[ks] = m.Fs[tl * 12 + 4 * ks + q];
+            float e = 0.f;
+            for (int mc = mt0; mc < mt1; mc += E2PF) {
+                if (mc != mt0) {
+#pragma unroll
+                    for (int jx = 0; jx < E2PF; ++jx)
+                        ph[jx] = e2_load_ph(PHrow, rowok && mc + jx < mt1, 16 * (mc + jx) + 4 * q, A, a.PH);
+                }
+#pragma unroll
+                for (int jx = 0; jx < E2PF; ++jx) {
+                    const int mt = mc + jx;
+                    if (mt < mt1) {   // uniform
+                        const f32x4 acc = e2_pre(m, mt, q, col, ph[jx], fB);
+                        const float4 w4 = *reinterpret_cast<const float4 *>(m.wee + 16 * mt + 4 * q);
+                        e += w4.x * tanh_f(acc[0]) + w4.y * tanh_f(acc[1]) + w4.z * tanh_f(acc[2]) + w4.w * tanh_f(acc[3]);
+                    }
+                }
+            }
+            e += __shfl_xor(e, 16, 64);
+            e += __shfl_xor(e, 32, 64);
+            if (q == 0) m.red[part * 64 + tl] = e;
+            __syncthreads();
+            if (tid < nrows) {
+                float v = 0.f;
+#pragma unroll
+                for (int pp = 0; pp < E2P; ++pp) v += m.red[pp * 64 + tid];
+                pd_st_sc1(eb + t0 + tid, v);
+            }
+        } else if (t0 < T) {
+            const int n = min(TT, T - t0) * NCH;
+            for (int i = tid; i < n; i += PD_THREADS) Fout[i] = 0.f;
+        }
+        PD_STAMP(2);
+        PD_PUBLISH(F_e + b * NTILE + k, s + 1);
+        // ---- C. softmax over the utterance (every workgroup of b for itself), context chunk k
+        PD_WAIT(pd_poll(F_e + b * NTILE, nact, 1, (unsigned)(s + 1)));
+        PD_STAMP(3);
+        {
+            float mx = -INFINITY;
+            for (int t = tid; t < len; t += PD_THREADS) {
+                const float v = pd_ld_sc1(eb + t);
+                al_cur[t] = v;
+                mx = fmaxf(mx, v);
+            }
+            mx = wave_max(mx);
+            if (lane == 0) sred[wave] = mx;
+            __syncthreads();
+            mx = sred[0];
+#pragma unroll
+            for (int i = 1; i < E2W; ++i) mx = fmaxf(mx, sred[i]);
+            float sum = 0.f;
+            for (int t = tid; t < len; t += PD_THREADS) {
+                const float pe = fast_exp(al_cur[t] - mx);
+                al_cur[t] = pe;
+                sum += pe;
+            }
+            sum = wave_sum(sum);
+            if (lane == 0) sred[16 + wave] = sum;
+            __syncthreads();
+            sum = 0.f;
+#pragma unroll
+            for (int i = 0; i < E2W; ++i) sum += sred[16 + i];
+            const float inv = 1.0f / sum;
+            float *alpha_s = a.alpha + (int64_t)s * BT + (int64_t)b * T;
+            for (int t = tid; t < T; t += PD_THREADS) {
+                const float av = t < len ? al_cur[t] * inv : 0.f;
+                al_cur[t] = av;
+                if (k == 0) alpha_s[t] = av;
+            }
+            __syncthreads();
+            const int c0 = k * EC, ncol = min(EC, E - c0);
+            const int ncg = EC / 4, nfg = PD_THREADS / ncg;
+            const int cg = tid % ncg, fg = tid / ncg;
+            if (fg < nfg) {
+                float4 acc = zero4();
+                if (4 * cg < ncol) {
+                    const float *hc = hb + c0 + 4 * cg;
+#pragma unroll 4
+                    for (int t = fg; t < len; t += nfg) {
+                        const float av = al_cur[t];
+                        const float4 h = ld4(hc + (int64_t)t * E);
+                        acc.x += av * h.x; acc.y += av * h.y; acc.z += av * h.z; acc.w += av * h.w;
+                    }
+                }
+                *reinterpret_cast<float4 *>(cred + fg * EC + 4 * cg) = acc;
+            }
+            __syncthreads();
+            if (tid < ncol) {
+                float v = 0.f;
+                for (int f = 0; f < nfg; ++f) v += cred[f * EC + tid];
+                pd_st_sc1(a.g + (int64_t)s * BE + (int64_t)b * E + c0 + tid, v);
+            }
+        }
+        PD_STAMP(4);
+        PD_PUBLISH(F_g + b * NTILE + k, s + 1);
+        // ---- D. cell jobs: 4 hidden units (all four gates) x 16 batch rows
+        for (int j = w; j < NJ * MTB; j += nWG) {
+            const int jt = j / MTB, mt = j - jt * MTB;
+            const int b0 = 16 * mt, j0 = 4 * jt, nr = min(16, B - b0);
+            PD_WAIT(pd_poll(F_g + b0 * NTILE, nr * NTILE, 1, (unsigned)(s + 1)) &&
+                    (s == 0 || pd_poll(F_S + mt, NJ, MTB, (unsigned)s)));
+            PD_STAMP(5);
+            {
+                const int i = lane & 15, bb = b0 + i;
+                const int gate = i >> 2, jj = j0 + (i & 3);
+                const int64_t wr = (int64_t)gate * Hd + jj;
+                Tile16Acc acc;
+                tile16_init(acc);
+                if (s > 0)
+                    pd_tile16_seg(acc, rS, bb < B ? (int)((((int64_t)s * B + bb) * Hd) * 4) : -1,
+                                  jj < Hd ? a.W_ss + wr * Hd : nullptr, Hd, a.W_ss);
+                pd_tile16_seg(acc, rG, bb < B ? (int)((((int64_t)s * B + bb) * E) * 4) : -1,
+                              jj < Hd ? a.W_gs + wr * E : nullptr, E, a.W_gs);
+                tile16_reduce(acc, red16);
+            }
+            if (tid < 64) {
+                const int bi = tid >> 2, ju = tid & 3;
+                const int bb = b0 + bi, jj = j0 + ju;
+                if (bb < B && jj < Hd) {
+                    int64_t y = a.targets[(int64_t)bb * L + s];
+                    y = y < 0 ? 0 : (y >= V ? V - 1 : y);
+                    float pre[4];
+#pragma unroll
+                    for (int g = 0; g < 4; ++g)
+                        pre[g] = tile16_get(red16, bi, g * 4 + ju) + a.Emb[y * 4 * Hd + g * Hd + jj] + a.b_gs[g * Hd + jj];
+                    const float ig = sigmoid_tanh_form(pre[0]), fg = sigmoid_tanh_form(pre[1]);
+                    const float gg = tanh_f(pre[2]), og = sigmoid_tanh_form(pre[3]);
+                    const float cprev = a.C[(int64_t)s * BH + (int64_t)bb * Hd + jj];
+                    const float c = fg * cprev + ig * gg;
+                    float *gd = a.gates + (int64_t)s * 4 * BH + (int64_t)bb * 4 * Hd;
+                    gd[0 * Hd + jj] = ig; gd[1 * Hd + jj] = fg; gd[2 * Hd + jj] = gg; gd[3 * Hd + jj] = og;
+                    a.C[(int64_t)(s + 1) * BH + (int64_t)bb * Hd + jj] = c;
+                    pd_st_sc1(a.S + (int64_t)(s + 1) * BH + (int64_t)bb * Hd + jj, og * tanh_f(c));
+                }
+            }
+            PD_STAMP(6);
+            PD_PUBLISH(F_S + j, s + 1);
+        }
+        // ---- E. state-projection jobs for the next step: 16 attention units x 16 batch rows
+        if (s + 1 < L) {
+            int jf = w - (NJ * MTB) % nWG;
+            if (jf < 0) jf += nWG;
+            for (int j = jf; j < NSP * MTB; j += nWG) {
+                const int nt = j / MTB, mt = j - nt * MTB;
+                const int n0 = 16 * nt, b0 = 16 * mt;
+                PD_WAIT(pd_poll(F_S + mt, NJ, MTB, (unsigned)(s + 1)));
+                PD_STAMP(7);
+                {
+                    const int i = lane & 15;
+                    Tile16Acc acc;
+                    tile16_init(acc);
+                    pd_tile16_seg(acc, rS, b0 + i < B ? (int)((((int64_t)(s + 1) * B + b0 + i) * Hd) * 4) : -1,
+                                  n0 + i < A ? a.W_se + (int64_t)(n0 + i) * Hd : nullptr, Hd, a.W_se);
+                    tile16_reduce(acc, red16);
+                }
+                if (tid < 256) {
+                    const int bi = tid >> 4, ni = tid & 15;
+                    if (b0 + bi < B && n0 + ni < A)
+                        pd_st_sc1(a.sproj + (int64_t)(s + 1) * BA + (int64_t)(b0 + bi) * A + n0 + ni,
+                                  tile16_get(red16, bi, ni));
+                }
+                PD_STAMP(8);
+                PD_PUBLISH(F_sp + j, s + 1);
+            }
+        }
+        PD_STAMP(9);
+    }
+}
+
+
 extern "C" int64_t asr_attdec_ws_floats(int B, int T, int E, int Hd, int L) {
     (void)E; (void)L;
     const int64_t A16 = (2 * Hd + 15) & ~15;
-    return (int64_t)B * T + 64 + A16 * 13 + 64;
+    // e_buf | tables | (persistent kernel) two energy slots, flag words, error word
+    const int64_t nflags = 2 * (int64_t)B * cdiv(T, TT) + (int64_t)(cdiv(Hd, 4) + cdiv(A16, 16)) * cdiv(B, 16);
+    return (int64_t)B * T + 64 + A16 * 13 + 64 + 2 * (int64_t)B * T + 64 + nflags + 64;
+}
+
+// Index (in floats) of the persistent kernel's sticky error word inside the workspace: set when an in-launch
+// wait timed out (the outputs are then garbage); the Python wrapper folds it into the outputs (NaN).
+extern "C" int64_t asr_attdec_err_offset(int B, int T, int E, int Hd, int L) {
+    (void)E; (void)L;
+    const int64_t A16 = (2 * Hd + 15) & ~15;
+    const int64_t nflags = 2 * (int64_t)B * cdiv(T, TT) + (int64_t)(cdiv(Hd, 4) + cdiv(2 * Hd, 16)) * cdiv(B, 16);
+    return (int64_t)B * T + 64 + A16 * 13 + 64 + 2 * (int64_t)B * T + 64 + nflags;
+}
+
+// diagnostics: a device buffer of B*ceil(T/64) * L * 10 uint64 that the next persistent launches fill with phase
+// time stamps (tools/dec_stamps.py); NULL switches it off.  Never set by the product path.
+static unsigned long long *g_attdec_stamps = nullptr;
+extern "C" void asr_attdec_debug_stamps(void *buf) { g_attdec_stamps = static_cast<unsigned long long *>(buf); }
+
+static int g_attdec_persist = 1;            // asr_attdec_persist(0) selects the one-launch-per-kernel loop (A/B, tests)
+extern "C" int asr_attdec_persist(int on) {
+    const int old = g_attdec_persist;
+    if (on == 0 || on == 1) g_attdec_persist = on;
+    return old;
 }
 
 struct GreedyParams {
@@ -756,6 +1159,7 @@ static int run_attdec_fwd(const asr_attdec_fwd_args *a, const GreedyParams *gp, 
     ASR_CHECK_HIP(hipMemsetAsync(a->S, 0, sizeof(float) * BH, st));
     ASR_CHECK_HIP(hipMemsetAsync(a->C, 0, sizeof(float) * BH, st));
     ASR_CHECK_HIP(hipMemsetAsync(a->sproj, 0, sizeof(float) * BA, st));
+    ASR_CHECK_HIP(hipMemsetAsync(a->ws + asr_attdec_err_offset(B, T, E, Hd, L), 0, sizeof(unsigned), st));
     const int vecPH = al16(a->PH) && A % 4 == 0;
     const size_t esm2 = energy_fwd2_smem(A);
     const bool use_v2 = vecPH && esm2 <= 150 * 1024;
@@ -775,6 +1179,48 @@ static int run_attdec_fwd(const asr_attdec_fwd_args *a, const GreedyParams *gp, 
     if (use_v2)
         hipLaunchKernelGGL(e2_prep_kernel, dim3(cdiv((int64_t)A16p * 12, 256)), dim3(256), 0, st, a->w_ee, a->W_fe,
                            A, A16p, tab);
+    // one launch for the whole loop when every workgroup of the (B x frame tile) grid gets a compute unit of its own
+    {
+        static int persist_on = -1, n_cu = 0;
+        if (persist_on < 0) {
+            const char *e = getenv("ASR_ATTDEC_PERSIST");
+            persist_on = (e && atoi(e) == 0) ? 0 : 1;
+            int dev = 0;
+            if (hipGetDevice(&dev) != hipSuccess ||
+                hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
+                n_cu = 0;
+        }
+        const int NTILE = cdiv(T, TT), MTB = cdiv(B, 16);
+        const size_t psm = attdec_persist_smem(A, T);
+        const int64_t big = (int64_t)0x7fff0000;
+        if (persist_on && g_attdec_persist && !gp && use_v2 && vecH && vecS && vecG && A % 16 == 0 && (int64_t)B * NTILE <= n_cu &&
+            psm <= 150 * 1024 && (L + 1) * BH * 4 < big && L * BE * 4 < big && L * BA * 4 < big) {
+            static thread_local bool attr3 = false;
+            if (!attr3) {
+                ASR_CHECK_HIP(hipFuncSetAttribute((const void *)attdec_fwd_persist_kernel,
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+                attr3 = true;
+            }
+            PDParams p;
+            p.a = *a;
+            p.tab = tab;
+            p.ebuf = tab + (int64_t)A16p * 13 + 64;
+            p.NTILE = NTILE;
+            p.MTB = MTB;
+            p.NJ = cdiv(Hd, 4);
+            p.NSP = cdiv(A, 16);
+            p.EC = ((cdiv(E, NTILE) + 3) / 4) * 4;
+            p.Tp = (T + 3) & ~3;
+            const int64_t nflags = 2 * (int64_t)B * NTILE + (int64_t)(p.NJ + p.NSP) * MTB;
+            p.flags = reinterpret_cast<unsigned *>(p.ebuf + 2 * BT + 64);
+            p.err = p.flags + nflags;
+            p.stamps = g_attdec_stamps;
+            ASR_CHECK_HIP(hipMemsetAsync(p.flags, 0, sizeof(unsigned) * (size_t)(nflags + 1), st));
+            hipLaunchKernelGGL(attdec_fwd_persist_kernel, dim3(B * NTILE), dim3(PD_THREADS), psm, st, p);
+            ASR_CHECK_LAUNCH("attdec_fwd_persist_kernel");
+            return ASR_OK;
+        }
+    }
     for (int s = 0; s < L; ++s) {
         const float *S_s = a->S + s * BH;
         float *sp_s = a->sproj + s * BA;

@@ -436,6 +436,16 @@ typedef struct {
 
 int64_t asr_attdec_ws_floats(int B, int T, int E, int Hd, int L);
 int asr_attdec_fwd(const asr_attdec_fwd_args *a, void *stream);
+/* asr_attdec_fwd runs the whole loop as ONE persistent launch when the (B x ceil(T/64)) workgroups each get a
+ * compute unit (in-launch hand-offs, csrc/attdec.hip), else four launches per label step.
+ * asr_attdec_persist(0 / 1) switches the one-launch form off / on (returns the previous setting; any other
+ * value only queries); environment variable ASR_ATTDEC_PERSIST=0 turns it off for the process.
+ * asr_attdec_err_offset: index (in floats) inside a->ws of a 4-byte word that is non-zero after the call iff an
+ * in-launch wait timed out (outputs invalid) -- fold it into the loss with asr_poison_if_flag. */
+int asr_attdec_persist(int on);
+/* diagnostics (tools/dec_stamps.py): device buffer for per-phase time stamps of the persistent launches, NULL = off */
+void asr_attdec_debug_stamps(void *buf);
+int64_t asr_attdec_err_offset(int B, int T, int E, int Hd, int L);
 
 /* Greedy search, batch 1: the beam_width == 1 path of Models/decoder.py:63-130.
  * Runs a->L (= hp.max_decoder_seq_len) steps with the argmax of step s fed back

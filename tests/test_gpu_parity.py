@@ -575,10 +575,14 @@ def test_config1_speech_commands_shape_vs_oracle():
     xd = x.to(dev).requires_grad_(True)
     loss = label_smoothing_loss(m(xd, lengths, tgt.to(dev)), tgt.to(dev), tl.to(dev))
     loss.backward()
-    assert abs(float(loss) - float(lr)) / abs(float(lr)) < LOSS_TOL
+    assert abs(float(loss.detach()) - float(lr.detach())) / abs(float(lr.detach())) < LOSS_TOL
     assert rel_err(xd.grad.cpu(), xr.grad) < GRAD_TOL
+    # a gradient that is zero up to cancellation (the bias inside the energy's tanh: ~5e-8 against 1e-2 for the
+    # model's largest entry, with a float32 reference on the other side) is judged against 1e-3 of that largest entry
+    floor = 1e-3 * max(float(q.grad.abs().max()) for q in ref.parameters())
     for (k, p), (_, q) in zip(m.named_parameters(), ref.named_parameters()):
-        assert rel_err(p.grad.cpu(), q.grad) < GRAD_TOL, k
+        err = float((p.grad.cpu() - q.grad).abs().max())
+        assert err < GRAD_TOL * max(float(q.grad.abs().max()), floor), (k, err)
 
 
 def test_dropout_between_layers():
@@ -941,3 +945,49 @@ def test_attmodel_gemm_precision_modes(mode, loss_tol, out_tol, grad_tol):
     for k, p in m.named_parameters():
         err = float((p.grad.cpu().double() - want[k].grad).abs().max())
         assert err < grad_tol * max(float(want[k].grad.abs().max()), floor), (k, err)
+
+
+@pytest.mark.parametrize("B,T,He,Hd,V,L,lens", [(32, 500, 320, 320, 1000, 12, "ragged"), (5, 130, 16, 8, 11, 6, [130, 64, 65, 1, 100]),
+                                                (18, 70, 8, 16, 9, 4, None), (3, 17, 4, 8, 7, 5, [17, 9, 4])])
+def test_decoder_persistent_loop_vs_per_step_launches(B, T, He, Hd, V, L, lens):
+    """The one-launch decoder loop (in-launch hand-offs between workgroups) against the four-launches-per-step
+    loop on the same inputs: outputs and every gradient (the backward consumes what the forward saved: S, C,
+    alpha, sproj, g, gates, Fc).  The two differ only in the order of the context sums."""
+    from asr_amd import _lib
+    from asr_amd.Models.decoder import Decoder
+    from oracle import ref_model as R
+    lib = _lib.load()
+    dev = _dev()
+    hp = R.make_hp(num_hidden_nodes_encoder=He, num_hidden_nodes_decoder=Hd, num_classes=V)
+    torch.manual_seed(T + Hd)
+    dec = Decoder(hp).to(dev).train()
+    if lens == "ragged":
+        lengths = torch.linspace(T, 300, B).long()
+    else:
+        lengths = torch.tensor(lens) if lens is not None else torch.randint(1, T + 1, (B,))
+    h = torch.randn(B, T, 2 * He)
+    for b in range(B):
+        h[b, lengths[b]:] = 0
+    tgt = torch.randint(0, V, (B, L)).to(dev)
+    w = torch.randn(B, L, V).to(dev)
+    res = []
+    was = lib.asr_attdec_persist(-1)
+    try:
+        for on in (0, 1):
+            lib.asr_attdec_persist(on)
+            dec.zero_grad(set_to_none=True)
+            hd = h.to(dev).requires_grad_(True)
+            y = dec(hd, lengths, tgt)
+            (y * w).sum().backward()
+            torch.cuda.synchronize()
+            res.append((y.detach().clone(), hd.grad.clone(), {k: p.grad.clone() for k, p in dec.named_parameters()}))
+    finally:
+        lib.asr_attdec_persist(was)
+    (y0, dh0, g0), (y1, dh1, g1) = res
+    assert bool(torch.isfinite(y1).all())
+    assert rel_err(y1.cpu(), y0.cpu()) < 1e-5
+    assert rel_err(dh1.cpu(), dh0.cpu()) < 2e-5
+    floor = 1e-3 * max(float(v.abs().max()) for v in g0.values())
+    for k in g0:
+        err = float((g1[k] - g0[k]).abs().max())
+        assert err < 2e-5 * max(float(g0[k].abs().max()), floor), (k, err)

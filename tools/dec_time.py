@@ -1,0 +1,23 @@
+"""Decoder forward at the config-2 shape: the persistent loop kernel against the per-step launches (HIP events)."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from asr_amd import _lib
+from asr_amd.Models.decoder import Decoder
+from bench import make_hp, time_kernel_events
+lib = _lib.load()
+dev = torch.device("cuda:0")
+hp = make_hp()
+torch.manual_seed(0)
+dec = Decoder(hp).to(dev).train()
+B, T, L = 32, 500, 100
+lengths = torch.linspace(500, 300, B).long()
+h = torch.randn(B, T, 640, device=dev)
+for b in range(B):
+    h[b, lengths[b]:] = 0
+tgt = torch.randint(0, 1000, (B, L), device=dev)
+for on in (0, 1, 0, 1):
+    lib.asr_attdec_persist(on)
+    with torch.no_grad():
+        dt = time_kernel_events(lambda: dec(h, lengths, tgt), 5)
+    print(f"persistent={on}: decoder forward {dt*1e3:.3f} ms ({dt*1e6/L:.1f} us per label step incl. hoisted GEMMs)", flush=True)
