@@ -738,6 +738,8 @@ static bool al16(const void *p) { return (((uintptr_t)p) & 15) == 0; }
 // resident, which the host guarantees by size (grid <= number of CUs, one 1024-thread workgroup
 // each).  alpha_{s-1} never leaves the workgroup: every workgroup of an utterance normalises the
 // utterance's energies itself and keeps the result in LDS for the next step's convolution.
+// 0 until the one-launch loop beats the per-step launches at the config-2 shape
+#define ATTDEC_PERSIST_DEFAULT 0
 #define PD_THREADS (E2W * 64)
 #define PD_SPIN_LIMIT (1 << 22)
 #define PD_OOB 0x7ffffff0
@@ -1121,9 +1123,17 @@ extern "C" int64_t asr_attdec_err_offset(int B, int T, int E, int Hd, int L) {
 static unsigned long long *g_attdec_stamps = nullptr;
 extern "C" void asr_attdec_debug_stamps(void *buf) { g_attdec_stamps = static_cast<unsigned long long *>(buf); }
 
-static int g_attdec_persist = 1;            // asr_attdec_persist(0) selects the one-launch-per-kernel loop (A/B, tests)
+static int g_attdec_persist = -1;           // asr_attdec_persist(0) selects the one-launch-per-kernel loop (A/B, tests)
+static int attdec_persist_on() {
+    if (g_attdec_persist < 0) {
+        const char *e = getenv("ASR_ATTDEC_PERSIST");
+        g_attdec_persist = (e && atoi(e) == 1) ? 1 : ATTDEC_PERSIST_DEFAULT;
+        if (e && atoi(e) == 0) g_attdec_persist = 0;
+    }
+    return g_attdec_persist;
+}
 extern "C" int asr_attdec_persist(int on) {
-    const int old = g_attdec_persist;
+    const int old = attdec_persist_on();
     if (on == 0 || on == 1) g_attdec_persist = on;
     return old;
 }
@@ -1181,10 +1191,8 @@ static int run_attdec_fwd(const asr_attdec_fwd_args *a, const GreedyParams *gp, 
                            A, A16p, tab);
     // one launch for the whole loop when every workgroup of the (B x frame tile) grid gets a compute unit of its own
     {
-        static int persist_on = -1, n_cu = 0;
-        if (persist_on < 0) {
-            const char *e = getenv("ASR_ATTDEC_PERSIST");
-            persist_on = (e && atoi(e) == 0) ? 0 : 1;
+        static int n_cu = -1;
+        if (n_cu < 0) {
             int dev = 0;
             if (hipGetDevice(&dev) != hipSuccess ||
                 hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
@@ -1193,7 +1201,7 @@ static int run_attdec_fwd(const asr_attdec_fwd_args *a, const GreedyParams *gp, 
         const int NTILE = cdiv(T, TT), MTB = cdiv(B, 16);
         const size_t psm = attdec_persist_smem(A, T);
         const int64_t big = (int64_t)0x7fff0000;
-        if (persist_on && g_attdec_persist && !gp && use_v2 && vecH && vecS && vecG && A % 16 == 0 && (int64_t)B * NTILE <= n_cu &&
+        if (attdec_persist_on() && !gp && use_v2 && vecH && vecS && vecG && A % 16 == 0 && (int64_t)B * NTILE <= n_cu &&
             psm <= 150 * 1024 && (L + 1) * BH * 4 < big && L * BE * 4 < big && L * BA * 4 < big) {
             static thread_local bool attr3 = false;
             if (!attr3) {

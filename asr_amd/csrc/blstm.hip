@@ -834,8 +834,21 @@ __global__ __launch_bounds__(256) void blstm_bwd_rs_kernel(
 #define BLSTM_ERR_WORD 1024     // sticky: set by a kernel whose poll timed out
 #define BLSTM_HX_OFF 2048
 
-static int bwd_unit_width(int B, int H) {   // 8 units per workgroup while the grid still fits one per CU
-    return (cdiv(H, 8) * 2 * cdiv(B, 16) <= 256 && cdiv(H, 8) <= 128) ? 8 : 16;
+// Hidden units per backward workgroup.  16 where the kernel is instantiated for it (H > 192): half as many,
+// fatter workgroups -- every workgroup publishes partial products for ALL units each step, so the exchange
+// traffic of a (direction, batch tile) group scales with its workgroup count, and the 40 extra MFMAs per step
+// cost less than that (config-2 layer: 3.41 -> 3.14 us per time step alone, 1867 -> 1757 us per launch inside
+// the training step).  8 below that, while the grid still fits one workgroup per CU.  ASR_BWD_UW=8 / 16 forces.
+static int bwd_unit_width(int B, int H) {
+    static int force = -1;
+    if (force < 0) {
+        const char *e = getenv("ASR_BWD_UW");
+        force = e ? atoi(e) : 0;
+    }
+    const bool fits8 = cdiv(H, 8) * 2 * cdiv(B, 16) <= 256 && cdiv(H, 8) <= 128;
+    if (force == 16 || !fits8) return 16;
+    if (force == 8) return 8;
+    return cdiv(cdiv(H, 16), 4) >= 4 ? 16 : 8;
 }
 
 extern "C" int64_t asr_blstm_ws_floats(int B, int H) {

@@ -439,7 +439,7 @@ int asr_attdec_fwd(const asr_attdec_fwd_args *a, void *stream);
 /* asr_attdec_fwd runs the whole loop as ONE persistent launch when the (B x ceil(T/64)) workgroups each get a
  * compute unit (in-launch hand-offs, csrc/attdec.hip), else four launches per label step.
  * asr_attdec_persist(0 / 1) switches the one-launch form off / on (returns the previous setting; any other
- * value only queries); environment variable ASR_ATTDEC_PERSIST=0 turns it off for the process.
+ * value only queries); environment variable ASR_ATTDEC_PERSIST=1 / 0 sets it for the process (default: off).
  * asr_attdec_err_offset: index (in floats) inside a->ws of a 4-byte word that is non-zero after the call iff an
  * in-launch wait timed out (outputs invalid) -- fold it into the loss with asr_poison_if_flag. */
 int asr_attdec_persist(int on);
