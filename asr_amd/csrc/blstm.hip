@@ -15,6 +15,8 @@
 // the reverse direction needs no per-sequence start offset) and writes h_t, c_t
 // and the activated gates.  HBM/L2 traffic per step is W_hh once (2*4H*H*4 B)
 // plus h_{t-1}; the step is latency-bound, not bandwidth-bound.
+#include <string.h>
+
 #include "tile16.cuh"
 
 __global__ __launch_bounds__(256) void blstm_fwd_step_kernel(
@@ -200,6 +202,31 @@ __device__ __forceinline__ bool tags_ok(const float4 &v, unsigned e) {
     return (((__float_as_uint(v.x) ^ e) | (__float_as_uint(v.y) ^ e) | (__float_as_uint(v.z) ^ e) |
              (__float_as_uint(v.w) ^ e)) & 1u) == 0u;
 }
+// bf16x3 split of the recurrent products (asr_blstm_precision): a value travels / sits in a register as ONE
+// 32-bit word {bf16 hi : bf16 lo}, hi = bf16(x), lo = bf16(x - hi) (round to nearest even); two such words give one
+// word of the hi operand and one of the lo operand of v_mfma_f32_16x16x32_bf16 with a byte permute each.
+typedef __bf16 bl_bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bl_bf16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned bl_hilo(float x) {
+    bl_bf16x2 h = {(__bf16)x, (__bf16)0.f};
+    const unsigned hb = __builtin_bit_cast(unsigned, h) & 0xffffu;
+    bl_bf16x2 l = {(__bf16)(x - __uint_as_float(hb << 16)), (__bf16)0.f};
+    return (hb << 16) | (__builtin_bit_cast(unsigned, l) & 0xffffu);
+}
+// eight {hi:lo} words (k = 0..7) -> the hi fragment and the lo fragment (8 bf16 each, k order kept)
+__device__ __forceinline__ void bl_frags(const unsigned (&w)[8], u32x4 &hi, u32x4 &lo) {
+    hi = u32x4{__builtin_amdgcn_perm(w[1], w[0], 0x07060302u), __builtin_amdgcn_perm(w[3], w[2], 0x07060302u),
+               __builtin_amdgcn_perm(w[5], w[4], 0x07060302u), __builtin_amdgcn_perm(w[7], w[6], 0x07060302u)};
+    lo = u32x4{__builtin_amdgcn_perm(w[1], w[0], 0x05040100u), __builtin_amdgcn_perm(w[3], w[2], 0x05040100u),
+               __builtin_amdgcn_perm(w[5], w[4], 0x05040100u), __builtin_amdgcn_perm(w[7], w[6], 0x05040100u)};
+}
+__device__ __forceinline__ f32x4 bl_mfma3(const u32x4 &ah, const u32x4 &al, const u32x4 &bh, const u32x4 &bl, f32x4 acc) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bl_bf16x8, al), __builtin_bit_cast(bl_bf16x8, bh), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bl_bf16x8, ah), __builtin_bit_cast(bl_bf16x8, bl), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bl_bf16x8, ah), __builtin_bit_cast(bl_bf16x8, bh), acc, 0, 0, 0);
+    return acc;
+}
+
 // wave-wide: wait until flags[0..n) >= want (n <= 128).  Returns false on timeout.
 __device__ __forceinline__ bool poll_flags(unsigned *flags, int n, unsigned want) {
     const int lane = threadIdx.x & 63;
@@ -221,7 +248,10 @@ __device__ __forceinline__ bool poll_flags(unsigned *flags, int n, unsigned want
 // loading only ITS 16 rows of h_{t-1} per step (20 KB instead of 40 KB at H = 320 -- the price of
 // an in-launch hand-off sits in the consumer CU's memory queue); (2, 1) when H % 8 != 0; (1, 1)
 // for up to 16 rows.
-template <int MT, int NT, int KQ4>
+// BF: the products on the bf16 matrix pipe (bf16x3 split, MT == 1, H % 32 == 0): the exchanged h travels as
+// {hi:lo} words, W_hh sits in registers pre-split, k-step ks = wave + 4 f (32 wide) of the KQ4 = ceil(H/128) steps
+// of a wave; everything else -- tags, issue order, cell update -- is the fp32 kernel's.
+template <int MT, int NT, int KQ4, bool BF = false>
 __global__ __launch_bounds__(256) void blstm_fwd_persist_kernel(
     const float *__restrict__ W_hh, float *__restrict__ G, float *__restrict__ Cs,
     float *__restrict__ Hout, int64_t ho_t, int64_t ho_b, int64_t hout_bytes,
@@ -238,13 +268,28 @@ __global__ __launch_bounds__(256) void blstm_fwd_persist_kernel(
     const int kb = (wave * 4 + q) * KQ;
     const int b0 = bt * MT * 16;
 
-    float4 wreg[NT][KQ4];
+    static_assert(!BF || MT == 1, "the bf16 form is built for one batch tile per workgroup");
+    float4 wreg[NT][BF ? 1 : KQ4];
+    u32x4 wbh[BF ? NT : 1][KQ4], wbl[BF ? NT : 1][KQ4];    // BF: W_hh fragments, hi and lo
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
         const int gate = i >> 2, j = jt * UN + 4 * nt + (i & 3);
         const float *wrow = W_hh + ((int64_t)d * 4 * H + gate * H + j) * H;
+        if (BF) {
 #pragma unroll
-        for (int f = 0; f < KQ4; ++f) wreg[nt][f] = (j < H && kb + 4 * f < H) ? ld4(wrow + kb + 4 * f) : zero4();
+            for (int f = 0; f < KQ4; ++f) {
+                const int k0 = 32 * (wave + 4 * f) + 8 * q;
+                unsigned ww[8];
+                const bool ok = j < H && k0 < H;      // H % 32 == 0: the eight floats are in range together
+                const float4 w0 = ok ? ld4(wrow + k0) : zero4(), w1 = ok ? ld4(wrow + k0 + 4) : zero4();
+                ww[0] = bl_hilo(w0.x); ww[1] = bl_hilo(w0.y); ww[2] = bl_hilo(w0.z); ww[3] = bl_hilo(w0.w);
+                ww[4] = bl_hilo(w1.x); ww[5] = bl_hilo(w1.y); ww[6] = bl_hilo(w1.z); ww[7] = bl_hilo(w1.w);
+                bl_frags(ww, wbh[nt][f], wbl[nt][f]);
+            }
+        } else {
+#pragma unroll
+            for (int f = 0; f < KQ4; ++f) wreg[nt][f] = (j < H && kb + 4 * f < H) ? ld4(wrow + kb + 4 * f) : zero4();
+        }
     }
     const bool owner = tid < MT * NT * 64;
     const int bl = tid / UN, u = tid % UN;                   // local batch row, local unit
@@ -276,8 +321,14 @@ __global__ __launch_bounds__(256) void blstm_fwd_persist_kernel(
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-        for (int f = 0; f < KQ4; ++f)
-            asm volatile("" ::"v"(wreg[nt][f].x), "v"(wreg[nt][f].y), "v"(wreg[nt][f].z), "v"(wreg[nt][f].w));
+        for (int f = 0; f < KQ4; ++f) {
+            if (BF) {
+                asm volatile("" ::"v"(wbh[nt][f].x), "v"(wbh[nt][f].y), "v"(wbh[nt][f].z), "v"(wbh[nt][f].w));
+                asm volatile("" ::"v"(wbl[nt][f].x), "v"(wbl[nt][f].y), "v"(wbl[nt][f].z), "v"(wbl[nt][f].w));
+            } else {
+                asm volatile("" ::"v"(wreg[nt][f].x), "v"(wreg[nt][f].y), "v"(wreg[nt][f].z), "v"(wreg[nt][f].w));
+            }
+        }
     asm volatile("" ::"v"(c), "v"(len));
     float sv[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};   // ig, fg, gg, og, c, h of the previous step
     int sv_g = OOB_OFF, sv_c = OOB_OFF, sv_h = OOB_OFF;   // their byte offsets
@@ -320,8 +371,10 @@ __global__ __launch_bounds__(256) void blstm_fwd_persist_kernel(
             // the 4 units of a batch row sit on 4 adjacent lanes: one 16-byte sc1 store per row
             // quad broadcasts on the VALU (DPP), not three trips through the LDS crossbar: the storing lane
             // is lane 0 of its quad (UN is a multiple of 4)
-            const float h1 = ASR_DPP(h, 0x55), h2 = ASR_DPP(h, 0xAA), h3 = ASR_DPP(h, 0xFF);
+            const float hx0 = BF ? __uint_as_float(bl_hilo(h)) : h;     // BF: the exchanged copy is the {hi:lo} word
+            const float h1 = ASR_DPP(hx0, 0x55), h2 = ASR_DPP(hx0, 0xAA), h3 = ASR_DPP(hx0, 0xFF);
             if ((u & 3) == 0 && !(dbg & 8)) {
+                const float h = hx0;
                 u32x4 pk = {__float_as_uint(h), __float_as_uint(h1), __float_as_uint(h2), __float_as_uint(h3)};
                 if (tagmode) {
                     const unsigned e = (unsigned)((s >> 1) & 1);
@@ -371,14 +424,19 @@ __global__ __launch_bounds__(256) void blstm_fwd_persist_kernel(
         }
         const int pbase = ((s - 1) & 1) * NJ * chunk;
         const unsigned want = (unsigned)(((s - 1) >> 1) & 1);
-        float4 a[MT][KQ4];
+        // exchange loads: 16-byte pieces a[m][f] of this lane's row(s) of h_{s-1}, first unit k = kof(f)
+        constexpr int NA = BF ? 2 * KQ4 : KQ4;
+        auto kof = [&](int f) -> int {
+            return BF ? 32 * (wave + 4 * (f >> 1)) + 8 * q + 4 * (f & 1) : kb + 4 * f;
+        };
+        float4 a[MT][NA];
         float pre[4];
         bool ok = true;
 #pragma unroll
         for (int m = 0; m < MT; ++m)
 #pragma unroll
-            for (int f = 0; f < KQ4; ++f) {
-                const int k = kb + 4 * f;             // first of 4 consecutive units
+            for (int f = 0; f < NA; ++f) {
+                const int k = kof(f);                 // first of 4 consecutive units
                 a[m][f] = ld4_sc1(rsrc, k < H ? (pbase + (k / UN) * chunk + (m * 16 + i) * UN + k % UN) * 4 : OOB_OFF);
             }
         __builtin_amdgcn_sched_barrier(0);   // keep the issue order: loads return in order
@@ -390,7 +448,7 @@ __global__ __launch_bounds__(256) void blstm_fwd_persist_kernel(
 #pragma unroll
         for (int m = 0; m < MT; ++m)
 #pragma unroll
-            for (int f = 0; f < KQ4; ++f) ok = ok & (tags_ok(a[m][f], want) | (kb + 4 * f >= H));
+            for (int f = 0; f < NA; ++f) ok = ok & (tags_ok(a[m][f], want) | (kof(f) >= H));
         if (tagmode && !(dbg & 1)) {
             for (int spins = 0; !__all(ok); ++spins) {   // wave-uniform
                 if (spins >= SPIN_LIMIT) {
@@ -405,17 +463,35 @@ __global__ __launch_bounds__(256) void blstm_fwd_persist_kernel(
 #pragma unroll
                 for (int m = 0; m < MT; ++m)
 #pragma unroll
-                    for (int f = 0; f < KQ4; ++f) {
-                        const int k = kb + 4 * f;
+                    for (int f = 0; f < NA; ++f) {
+                        const int k = kof(f);
                         a[m][f] = ld4_sc1(rsrc, k < H ? (pbase + (k / UN) * chunk + (m * 16 + i) * UN + k % UN) * 4 : OOB_OFF);
                     }
                 __builtin_amdgcn_sched_barrier(0);   // all loads in flight before the first check
 #pragma unroll
                 for (int m = 0; m < MT; ++m)
 #pragma unroll
-                    for (int f = 0; f < KQ4; ++f) ok = ok & (tags_ok(a[m][f], want) | (kb + 4 * f >= H));
+                    for (int f = 0; f < NA; ++f) ok = ok & (tags_ok(a[m][f], want) | (kof(f) >= H));
             }
         }
+        if (BF) {
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int f = 0; f < KQ4; ++f) {
+                    const float4 lo4 = a[0][2 * f], hi4 = a[0][2 * f + 1];
+                    const unsigned ww[8] = {__float_as_uint(lo4.x), __float_as_uint(lo4.y), __float_as_uint(lo4.z),
+                                            __float_as_uint(lo4.w), __float_as_uint(hi4.x), __float_as_uint(hi4.y),
+                                            __float_as_uint(hi4.z), __float_as_uint(hi4.w)};
+                    u32x4 ah, al;
+                    bl_frags(ww, ah, al);
+                    acc = bl_mfma3(ah, al, wbh[nt][f], wbl[nt][f], acc);
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) red[s & 1][wave][0][nt][q * 4 + r][i] = acc[r];
+            }
+        } else {
 #pragma unroll
         for (int m = 0; m < MT; ++m)
 #pragma unroll
@@ -431,6 +507,7 @@ __global__ __launch_bounds__(256) void blstm_fwd_persist_kernel(
 #pragma unroll
                 for (int r = 0; r < 4; ++r) red[s & 1][wave][m][nt][q * 4 + r][i] = acc0[r] + acc1[r];
             }
+        }
         // every wave consumes its gate loads here (not only the owner lanes): no load is left
         // pending across the loop's back edge, where the compiler would have to drain the
         // whole queue before reusing the registers
@@ -570,7 +647,9 @@ __global__ __launch_bounds__(256) void blstm_bwd_persist_kernel(
 // fixed order (deterministic).  Compared with exchanging dG itself this moves
 // 16*H*4 B out and in per workgroup and step instead of 16*4H*4 B in, and the
 // MFMA operands never come from another workgroup.
-template <int UW, int NMT>
+// BF: the products on the bf16 matrix pipe (bf16x3 split): W_hh's rows sit in registers as hi / lo fragments, the
+// workgroup's own dG goes through LDS as {hi:lo} words; the exchanged partial products stay fp32.
+template <int UW, int NMT, bool BF = false>
 __global__ __launch_bounds__(256) void blstm_bwd_rs_kernel(
     const float *__restrict__ W_hh, float *__restrict__ G, const float *__restrict__ Cs,
     const float *__restrict__ dHout, int64_t dho_t, int64_t dho_b, const int32_t *__restrict__ lengths,
@@ -579,7 +658,8 @@ __global__ __launch_bounds__(256) void blstm_bwd_rs_kernel(
     constexpr int KL = 4 * UW, KS = KL / 4, DSTR = KL + 4;
     constexpr int NI = 16 * UW / 4;     // 16-byte items per source workgroup (16 rows x UW/4)
     constexpr int NG = 256 / NI;        // thread groups that split the sources
-    __shared__ float dgl[16][DSTR];
+    constexpr int KSB = KL / 32;        // BF: k-steps of 32 own gate rows
+    __shared__ __attribute__((aligned(16))) float dgl[16][DSTR];
     __shared__ __attribute__((aligned(16))) float part[NG][NI][4];
     __shared__ int s_abort;
     const int jt = blockIdx.x, d = blockIdx.y, bt = blockIdx.z, NJT = gridDim.x, NBT = gridDim.z;
@@ -589,16 +669,32 @@ __global__ __launch_bounds__(256) void blstm_bwd_rs_kernel(
     const int MTILES = (H + 15) / 16, Hp = MTILES * 16;
 
     // A operand: W_hh[own row k][j = 16*mt + i], k = 4*ks + q  (resident for all T steps)
-    float areg[NMT][KS];
+    float areg[NMT][BF ? 1 : KS];
+    u32x4 abh[BF ? NMT : 1][KSB], abl[BF ? NMT : 1][KSB];
 #pragma unroll
     for (int mtl = 0; mtl < NMT; ++mtl) {
         const int jc = 16 * (wave + 4 * mtl) + i;
+        if (BF) {
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-            const int k = 4 * ks + q;
-            const int g = k / UW, ju = k % UW;
-            const bool ok = jc < H && j0 + ju < H;
-            areg[mtl][ks] = ok ? W_hh[((int64_t)d * 4 * H + g * H + j0 + ju) * H + jc] : 0.f;
+            for (int kb2 = 0; kb2 < KSB; ++kb2) {
+                unsigned ww[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const int k = 32 * kb2 + 8 * q + e;
+                    const int g = k / UW, ju = k % UW;
+                    const bool ok = jc < H && j0 + ju < H;
+                    ww[e] = bl_hilo(ok ? W_hh[((int64_t)d * 4 * H + g * H + j0 + ju) * H + jc] : 0.f);
+                }
+                bl_frags(ww, abh[mtl][kb2], abl[mtl][kb2]);
+            }
+        } else {
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const int k = 4 * ks + q;
+                const int g = k / UW, ju = k % UW;
+                const bool ok = jc < H && j0 + ju < H;
+                areg[mtl][ks] = ok ? W_hh[((int64_t)d * 4 * H + g * H + j0 + ju) * H + jc] : 0.f;
+            }
         }
     }
     const bool owner = tid < 16 * UW;
@@ -630,9 +726,18 @@ __global__ __launch_bounds__(256) void blstm_bwd_rs_kernel(
     // the set-up loads are consumed here: a load pending at the loop entry would cost a
     // conservative queue drain in every iteration
 #pragma unroll
-    for (int mtl = 0; mtl < NMT; ++mtl)
+    for (int mtl = 0; mtl < NMT; ++mtl) {
+        if (BF) {
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) asm volatile("" ::"v"(areg[mtl][ks]));
+            for (int kb2 = 0; kb2 < KSB; ++kb2) {
+                asm volatile("" ::"v"(abh[mtl][kb2].x), "v"(abh[mtl][kb2].y), "v"(abh[mtl][kb2].z), "v"(abh[mtl][kb2].w));
+                asm volatile("" ::"v"(abl[mtl][kb2].x), "v"(abl[mtl][kb2].y), "v"(abl[mtl][kb2].z), "v"(abl[mtl][kb2].w));
+            }
+        } else {
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) asm volatile("" ::"v"(areg[mtl][ks]));
+        }
+    }
     asm volatile("" ::"v"(dcarry), "v"(len));
 
     struct Act { float ig, fg, gg, og, cc, cp, dh; };
@@ -676,19 +781,39 @@ __global__ __launch_bounds__(256) void blstm_bwd_rs_kernel(
         sv_g = valid ? (int)((((((int64_t)(d == 0 ? T - 1 - s : s)) * B + b) * 2 + d) * 4 * H + j) * 4) : OOB_OFF;
         (void)growb;
         if (owner) {
-            dgl[bi][ju] = d0; dgl[bi][UW + ju] = d1; dgl[bi][2 * UW + ju] = d2; dgl[bi][3 * UW + ju] = d3;
+            if (BF) {   // {hi:lo} words: split once by the owner, not by every reader
+                dgl[bi][ju] = __uint_as_float(bl_hilo(d0)); dgl[bi][UW + ju] = __uint_as_float(bl_hilo(d1));
+                dgl[bi][2 * UW + ju] = __uint_as_float(bl_hilo(d2)); dgl[bi][3 * UW + ju] = __uint_as_float(bl_hilo(d3));
+            } else {
+                dgl[bi][ju] = d0; dgl[bi][UW + ju] = d1; dgl[bi][2 * UW + ju] = d2; dgl[bi][3 * UW + ju] = d3;
+            }
         }
         __syncthreads();
         if (s + 1 < T) {   // uniform
             f32x4 acc[NMT];
 #pragma unroll
             for (int mtl = 0; mtl < NMT; ++mtl) acc[mtl] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (BF) {
+#pragma unroll
+                for (int kb2 = 0; kb2 < KSB; ++kb2) {
+                    const float4 x0 = *reinterpret_cast<const float4 *>(&dgl[i][32 * kb2 + 8 * q]);
+                    const float4 x1 = *reinterpret_cast<const float4 *>(&dgl[i][32 * kb2 + 8 * q + 4]);
+                    const unsigned ww[8] = {__float_as_uint(x0.x), __float_as_uint(x0.y), __float_as_uint(x0.z),
+                                            __float_as_uint(x0.w), __float_as_uint(x1.x), __float_as_uint(x1.y),
+                                            __float_as_uint(x1.z), __float_as_uint(x1.w)};
+                    u32x4 bh, bl;
+                    bl_frags(ww, bh, bl);
+#pragma unroll
+                    for (int mtl = 0; mtl < NMT; ++mtl) acc[mtl] = bl_mfma3(abh[mtl][kb2], abl[mtl][kb2], bh, bl, acc[mtl]);
+                }
+            } else {
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
                 const float bv = dgl[i][4 * ks + q];
 #pragma unroll
                 for (int mtl = 0; mtl < NMT; ++mtl)
                     acc[mtl] = __builtin_amdgcn_mfma_f32_16x16x4f32(areg[mtl][ks], bv, acc[mtl], 0, 0, 0);
+            }
             }
             if (!(dbg & 8)) {
 #pragma unroll
@@ -873,6 +998,42 @@ extern "C" void asr_debug_set(int flags) {
 
 static bool al16p(const void *p) { return (((uintptr_t)p) & 15) == 0; }
 
+// Arithmetic of the recurrent products h W_hh^T / dG W_hh inside the persistent kernels: 0 = exact fp32
+// (v_mfma_f32_16x16x4_f32), 1 = bf16x3 split on v_mfma_f32_16x16x32_bf16 (shapes with H % 32 == 0, one batch
+// tile per workgroup; others stay fp32).  ASR_BLSTM_PRECISION = f32 | bf16x3 sets the start-up value.
+#define BLSTM_PRECISION_DEFAULT 1
+static int g_blstm_precision = -1;
+static int blstm_precision() {
+    if (g_blstm_precision < 0) {
+        const char *e = getenv("ASR_BLSTM_PRECISION");
+        g_blstm_precision = BLSTM_PRECISION_DEFAULT;
+        if (e && (!strcmp(e, "f32") || !strcmp(e, "0"))) g_blstm_precision = 0;
+        if (e && (!strcmp(e, "bf16x3") || !strcmp(e, "1"))) g_blstm_precision = 1;
+    }
+    return g_blstm_precision;
+}
+extern "C" int asr_blstm_precision(int mode) {
+    const int old = blstm_precision();
+    if (mode == 0 || mode == 1) g_blstm_precision = mode;
+    return old;
+}
+
+template <int NT>
+static bool launch_fwd_persist_bf(int nks, dim3 grid, hipStream_t st, const float *W_hh, float *G, float *Cs,
+                                  float *Hout, int64_t ho_t, int64_t ho_b, const int32_t *lengths, int T, int B,
+                                  int H, int s0, int s1, float *hx, unsigned *flags, unsigned *err) {
+    const int64_t hout_bytes = ((int64_t)(T - 1) * ho_t + (int64_t)(B - 1) * ho_b + 2 * H) * 4;
+#define FWD_BF_CASE(K)                                                                                       \
+    case K:                                                                                                  \
+        hipLaunchKernelGGL((blstm_fwd_persist_kernel<1, NT, K, true>), grid, dim3(256), 0, st, W_hh, G, Cs,  \
+                           Hout, ho_t, ho_b, hout_bytes, lengths, T, B, H, s0, s1, hx, flags, err, g_dbg,    \
+                           g_tagmode);                                                                       \
+        return true;
+    switch (nks) { FWD_BF_CASE(1) FWD_BF_CASE(2) FWD_BF_CASE(3) FWD_BF_CASE(4) }
+#undef FWD_BF_CASE
+    return false;
+}
+
 template <int MT, int NT>
 static bool launch_fwd_persist(int kq4, dim3 grid, hipStream_t st, const float *W_hh, float *G, float *Cs,
                                float *Hout, int64_t ho_t, int64_t ho_b, const int32_t *lengths, int T, int B,
@@ -919,7 +1080,14 @@ extern "C" int asr_blstm_fwd_range(const float *W_hh, float *G, float *Cs, float
             ASR_CHECK_HIP(hipMemsetAsync(hx, 0xFF, sizeof(float) * (size_t)4 * NJ * MT * 64, st));
     }
     bool ok;
-    if (MT == 1) {
+    const bool bf = blstm_precision() == 1 && H % 32 == 0 && H <= 512 && g_tagmode;
+    if (bf && MT == 1) {
+        ok = launch_fwd_persist_bf<1>(cdiv(H / 32, 4), dim3(NJ, 2, 1), st, W_hh, G, Cs, Hout, ho_t, ho_b, lengths, T, B,
+                                      H, s0, s1, hx, flags, err);
+    } else if (bf && g_fwd_form == 0) {
+        ok = launch_fwd_persist_bf<2>(cdiv(H / 32, 4), dim3(H / 8, 2, 2), st, W_hh, G, Cs, Hout, ho_t, ho_b, lengths, T,
+                                      B, H, s0, s1, hx, flags, err);
+    } else if (MT == 1) {
         ok = launch_fwd_persist<1, 1>(kq4, dim3(NJ, 2, 1), st, W_hh, G, Cs, Hout, ho_t, ho_b, lengths, T, B, H, s0,
                                       s1, hx, flags, err);
     } else if (H % 8 == 0 && g_fwd_form == 0) {   // two batch tiles on separate workgroups of 8 units
@@ -976,9 +1144,18 @@ extern "C" int asr_blstm_bwd_range(const float *W_hh, const float *W_hhT, float 
                 if (g_tagmode)
                     ASR_CHECK_HIP(hipMemsetAsync(xP, 0xFF, (size_t)xbytes * 2 * NBT, st));
             }
-#define RS_CASE(U, N)                                                                                   \
-    hipLaunchKernelGGL((blstm_bwd_rs_kernel<U, N>), g2, dim3(256), 0, st, W_hh, G, Cs, dHout, dho_t,   \
-                       dho_b, lengths, dh_bytes, T, B, H, s0, s1, dc_ws, xP, flags, err, g_dbg, g_tagmode)
+            const bool bfb = blstm_precision() == 1;
+#define RS_CASE(U, N)                                                                                        \
+    do {                                                                                                     \
+        if (bfb)                                                                                             \
+            hipLaunchKernelGGL((blstm_bwd_rs_kernel<U, N, true>), g2, dim3(256), 0, st, W_hh, G, Cs, dHout,  \
+                               dho_t, dho_b, lengths, dh_bytes, T, B, H, s0, s1, dc_ws, xP, flags, err,      \
+                               g_dbg, g_tagmode);                                                            \
+        else                                                                                                 \
+            hipLaunchKernelGGL((blstm_bwd_rs_kernel<U, N>), g2, dim3(256), 0, st, W_hh, G, Cs, dHout, dho_t, \
+                               dho_b, lengths, dh_bytes, T, B, H, s0, s1, dc_ws, xP, flags, err, g_dbg,      \
+                               g_tagmode);                                                                   \
+    } while (0)
             if (uw == 8) {
                 switch (nmt) {
                     case 1: RS_CASE(8, 1); break;

@@ -260,6 +260,11 @@ int asr_clip_adam_step(const asr_tensor_list *params, const asr_tensor_list *gra
  *         timed out.  ws == NULL selects the one-launch-per-time-step kernels.
  */
 int64_t asr_blstm_ws_floats(int B, int H);
+/* Arithmetic of the recurrent products inside the persistent kernels (the reference: fp32, torch.nn.LSTM):
+ * 0 exact fp32 products, 1 the bf16x3 split on the bf16 matrix pipe (fp32 accumulate; H % 32 == 0 in the forward,
+ * other shapes stay fp32).  Returns the previous mode; other values only query.  Start-up value: environment
+ * variable ASR_BLSTM_PRECISION = f32 | bf16x3. */
+int asr_blstm_precision(int mode);
 int asr_blstm_fwd(const float *W_hh, float *G, float *Cs, float *Hout,
                   int64_t ho_t, int64_t ho_b, const int32_t *lengths,
                   int T, int B, int H, float *ws, void *stream);

@@ -41,6 +41,17 @@ def _default_gemm_precision(request):
         return
     from asr_amd import _lib
     lib = _lib.load()
-    start = lib.asr_gemm_precision(-1)
+    start, start_rec = lib.asr_gemm_precision(-1), lib.asr_blstm_precision(-1)
     yield
     lib.asr_gemm_precision(start)
+    lib.asr_blstm_precision(start_rec)
+
+
+@pytest.fixture(params=[0, 1], ids=["recurrence-f32", "recurrence-bf16x3"])
+def blstm_mode(request):
+    """Arithmetic of the recurrent products inside the persistent BLSTM kernels (asr_blstm_precision)."""
+    from asr_amd import _lib
+    lib = _lib.load()
+    old = lib.asr_blstm_precision(request.param)
+    yield request.param
+    lib.asr_blstm_precision(old)

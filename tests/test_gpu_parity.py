@@ -200,7 +200,7 @@ def test_loss_kernel_vs_oracle(B, L, V, T_norm, B_norm):
                                             (18, 21, 10, 32, 3, None), (2, 40, 240, 320, 2, [40, 31]),
                                             (35, 9, 5, 8, 1, None), (2, 1, 4, 8, 2, [1, 1]),
                                             (33, 12, 6, 64, 2, None)])
-def test_blstm_vs_oracle(B, T, D, H, N, lens):
+def test_blstm_vs_oracle(B, T, D, H, N, lens, blstm_mode):
     from asr_amd.Models.encoder import Encoder
     from oracle import ref_model as R
     dev = _dev()
@@ -233,7 +233,7 @@ def test_blstm_vs_oracle(B, T, D, H, N, lens):
     assert not persistent_error_flags()
 
 
-def test_persistent_and_stepwise_recurrence_agree():
+def test_persistent_and_stepwise_recurrence_agree(blstm_mode):
     """The one-launch-per-layer (in-launch hand-off) kernels against the
     one-launch-per-time-step kernels at the production width, ragged batch of 32;
     also checks that no in-launch wait ever timed out."""

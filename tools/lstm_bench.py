@@ -25,11 +25,13 @@ def fwd():
 def bwd():
     lib.asr_blstm_bwd(W.data_ptr(), WT.data_ptr(), G.data_ptr(), Cs.data_ptr(), dH.data_ptr(), B * 2 * H, 2 * H,
                       lengths.data_ptr(), dc.data_ptr(), T, B, H, ws.data_ptr(), st)
-for dbg in (0, 512, 512 + 256, 1):
-    lib.asr_debug_set(dbg)
-    G.copy_(G0)
-    tf = time_kernel_events(fwd, 3)
-    tb = time_kernel_events(bwd, 3)
-    print(f"dbg={dbg}: fwd {tf*1e6/T:6.2f} us/step   bwd {tb*1e6/T:6.2f} us/step", flush=True)
+for prec in (0, 1):
+    lib.asr_blstm_precision(prec)
+    for dbg in (0, 1):
+        lib.asr_debug_set(dbg)
+        G.copy_(G0)
+        tf = time_kernel_events(fwd, 3)
+        tb = time_kernel_events(bwd, 3)
+        print(f"precision={prec} dbg={dbg}: fwd {tf*1e6/T:6.2f} us/step   bwd {tb*1e6/T:6.2f} us/step", flush=True)
 lib.asr_debug_set(0)
 print("err", int(ws.view(torch.int32)[1024]))

@@ -1,5 +1,6 @@
 """Config 2 at full size (dropout off): the float64 CPU oracle (oracle/ref_model.py, ~1-2 min on the box's host
-cores) against the HIP path in GEMM modes 0 (exact fp32 products), 1 (bf16x3) and 2 (bf16): loss, youtput and every
+cores) against the HIP path in the arithmetic modes of the hoisted products (asr_gemm_precision: exact fp32, bf16x3, bf16) and of
+the recurrent products (asr_blstm_precision: exact fp32, bf16x3): loss, youtput and every
 gradient, max |err| / max |reference| per tensor.  GPU box only."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -29,8 +30,10 @@ want = {k: p.grad for k, p in ref.named_parameters()}
 gmax = max(float(g.abs().max()) for g in want.values())
 m = m.to(dev).train()
 xd, td, tld = x.to(dev), tgt.to(dev), tl.to(dev)
-for mode, tag in ((0, "f32"), (1, "bf16x3"), (2, "bf16")):
+for mode, rec, tag in ((0, 0, "products f32, recurrence f32"), (1, 0, "products bf16x3, recurrence f32"),
+                       (1, 1, "products bf16x3, recurrence bf16x3"), (2, 0, "products bf16, recurrence f32")):
     lib.asr_gemm_precision(mode)
+    lib.asr_blstm_precision(rec)
     m.zero_grad(set_to_none=True)
     y = m(xd, lengths, td)
     loss = label_smoothing_loss(y, td, tld, hp.T_norm, hp.B_norm)
@@ -45,3 +48,4 @@ for mode, tag in ((0, "f32"), (1, "bf16x3"), (2, "bf16")):
           + ", ".join(f"{k} {v:.1e} (|g|max {float(want[k].abs().max()):.1e})" for k, v in worst), flush=True)
 print(f"largest gradient entry of the model: {gmax:.3e}")
 lib.asr_gemm_precision(1)
+lib.asr_blstm_precision(0)
