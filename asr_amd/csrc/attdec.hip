@@ -21,6 +21,7 @@
 // full-line global reads and read back transposed, bank-conflict free.
 // HBM/L3 traffic per step: PH once (energy) + hbatch once (ctx) = 2*B*T*A*4 B.
 #include <stdlib.h>
+#include <algorithm>
 
 #include "tile16.cuh"
 
@@ -720,38 +721,47 @@ static size_t energy_bwd2_smem(int A) {
 static bool al16(const void *p) { return (((uintptr_t)p) & 15) == 0; }
 
 // ===================================================== persistent forward ==
-// The whole teacher-forced loop of Models/decoder.py:52-60 in ONE launch.  Workgroup (b, k) of the
-// grid B x ceil(T/64) -- one per compute unit, all resident -- owns 64 frames of utterance b for the
-// energies and one column chunk of the context; the M = 32 products of a step (cell input, state
-// projection) are 16 x 16 tile jobs dealt over the same workgroups.  Per label step the data flows
-//   sproj_s[b]  -> energy (b, k)      -> e[b, 64 frames]                      (edge E)
-//   e[b, :]     -> softmax + context  -> alpha_s[b], g_s[b, chunk k]          (edge G)
-//   g_s, S_s    -> cell job (4 units x 16 rows) -> S_{s+1}, C_{s+1}, gates_s  (edge S)
-//   S_{s+1}     -> state-projection job (16 a x 16 rows) -> sproj_{s+1}       (edge P)
-// through the saved-activation tensors themselves (one slab per step: nothing is overwritten inside
-// the launch; the energies use two parity slots).  Hand-off form (MI355X_MICROARCH.md, valid forms,
-// flag row): payload stores sc1 -> every storing wave s_waitcnt vmcnt(0) -> workgroup barrier -> one
-// lane stores the producer's flag = step + 1 (sc1); consumer: wave 0 polls the flags it needs with
-// sc1 loads (bounded: a poll that runs out sets *err and the workgroup leaves, the others then run
-// out the same way, so the grid always drains) -> workgroup barrier -> every load of handed-off
-// bytes is an sc1 load.  Nothing depends on dispatch order or placement; it needs all workgroups
-// resident, which the host guarantees by size (grid <= number of CUs, one 1024-thread workgroup
-// each).  alpha_{s-1} never leaves the workgroup: every workgroup of an utterance normalises the
-// utterance's energies itself and keeps the result in LDS for the next step's convolution.
-// 0 until the one-launch loop beats the per-step launches at the config-2 shape
-#define ATTDEC_PERSIST_DEFAULT 0
-#define PD_THREADS (E2W * 64)
-#define PD_SPIN_LIMIT (1 << 22)
+// The whole teacher-forced loop of Models/decoder.py:52-60 in ONE launch, with everything a step re-reads kept
+// ON CHIP for all L steps.  Workgroup (b, k) of the grid B x ceil(T/64) -- 512 threads, one per compute unit, all
+// resident -- holds in REGISTERS
+//   * the 64-frame tile k of PH[b] (all attention units): 20 float4 per lane in the C/D layout of the energy MFMAs,
+//   * the column chunk k of hbatch[b] (all frames): 20 float4 per lane for the context sum,
+// so a step's energies and context cost no memory traffic at all (the per-step kernels stream 2 x 41 MB per step).
+// The M = 32 products of a step are 16 x 16 tile jobs on the same workgroups: cell jobs (4 hidden units x 16 batch
+// rows) on workgroups [0, NJ*MTB), state-projection jobs (16 attention units x 16 rows) on the next NSP*MTB.
+// Per label step the data crosses workgroups four times:
+//   sproj_s[b]     -> energy (b, k)                           (edge P, 2.5 KB in per workgroup)
+//   e[b, 64 frames]-> softmax + context chunk, all (b, *)     (edge E, 2 KB in)
+//   g_s[b, chunk]  -> cell jobs of b's batch tile             (edge G, 41 KB in per job)
+//   S_{s+1}        -> state-projection jobs, and the W_ss S term of the next step's cell jobs (edge S, 20 KB in)
+// Hand-off: as in csrc/blstm.hip -- 16-byte write-through (sc1) stores of an EXCHANGED COPY whose every float carries
+// the step's epoch bit (s >> 1) & 1 in its mantissa LSB (<= 1 ulp; the saved activations S, g, sproj, alpha are
+// stored untouched beside it), two parity slots per edge pre-filled with 0xFF, and the consumer re-loads (sc1) until
+// every tag matches: no flag, no store drain, no fence.  A slot is rewritten two steps later; by then every reader
+// is past it (each edge's producer at step s + 2 depends, through the chain above, on every consumer of its step-s
+// data having produced something later).  Bounded spins: a wait that runs out sets *err and the workgroup leaves,
+// the others then run out the same way, so the grid always drains.  Weights of a job (static) are fetched BEFORE
+// its wait, so only the handed-off operand's latency is on the chain.  alpha_{s-1} never leaves the workgroup:
+// every workgroup of an utterance normalises the utterance's energies itself and keeps them in LDS for the
+// next step's convolution.
+#define ATTDEC_PERSIST_DEFAULT 1
+#define PD_THREADS 512
+#define PD_WAVES (PD_THREADS / 64)
+#define PD_MTP 20          // 16-unit tiles of the attention dimension per wave (2 parts): A <= 640
+#define PD_HF 20           // frames per thread of the context chunk
+#define PD_AL (32 * PD_MTP)   // attention units the LDS tables are padded to (zeros past A)
+#define PD_KF 5            // float4 per lane of a job's K slot: K <= 32 slots x 20 = 640
+#define PD_SPIN_LIMIT (1 << 20)
 #define PD_OOB 0x7ffffff0
 typedef unsigned int pd_u32x4 __attribute__((ext_vector_type(4)));
 
 struct PDParams {
     asr_attdec_fwd_args a;
     const float *tab;      // padded W_fe / w_ee tables (e2_prep_kernel)
-    float *ebuf;           // [2][B][T] energies, parity slots
-    unsigned *flags;       // F_e [B*NTILE] | F_g [B*NTILE] | F_S [NJ*MTB] | F_sp [NSP*MTB]
+    float *xch;            // exchange area (tagged copies, two parity slots each): X_sp | X_e | X_g | X_S
     unsigned *err;         // sticky error word
-    int NTILE, EC, NJ, NSP, MTB, Tp;
+    int NTILE, EC, NJ, NSP, MTB, nfg, A16, Tp, Tal;
+    int o_e, o_g, o_S, xch_bytes;
     unsigned long long *stamps;   // diagnostics only (asr_attdec_debug_stamps): [workgroup][step][PD_NSTAMP] 100 MHz clock
 };
 #define PD_NSTAMP 10
@@ -765,357 +775,493 @@ __device__ __forceinline__ float4 pd_ld4_sc1(__amdgpu_buffer_rsrc_t r, int byte_
     pd_u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, 16 /* sc1 */);
     return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
 }
-__device__ __forceinline__ float pd_ld_sc1(const float *p) {
-    return __uint_as_float(__hip_atomic_load(reinterpret_cast<const unsigned *>(p), __ATOMIC_RELAXED,
-                                             __HIP_MEMORY_SCOPE_AGENT));
+__device__ __forceinline__ int pd_opaque(int x) {
+    asm volatile("" : "+v"(x));
+    return x;
 }
-__device__ __forceinline__ void pd_st_sc1(float *p, float v) {
-    __hip_atomic_store(reinterpret_cast<unsigned *>(p), __float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+__device__ __forceinline__ unsigned pd_tag(float v, unsigned e) { return (__float_as_uint(v) & ~1u) | e; }
+__device__ __forceinline__ void pd_st4_tag(__amdgpu_buffer_rsrc_t r, int byte_off, const float4 &v, unsigned e) {
+    const pd_u32x4 pk = {pd_tag(v.x, e), pd_tag(v.y, e), pd_tag(v.z, e), pd_tag(v.w, e)};
+    __builtin_amdgcn_raw_buffer_store_b128(pk, r, byte_off, 0, 16 /* sc1 */);
 }
-// one wave: wait until flags[i * stride] >= want for i < n.  false on timeout.
-__device__ __forceinline__ bool pd_poll(const unsigned *flags, int n, int stride, unsigned want) {
-    const int lane = threadIdx.x & 63;
-    for (int spins = 0; spins < PD_SPIN_LIMIT; ++spins) {
-        bool ok = true;
-        for (int i = lane; i < n; i += 64)
-            ok = ok && __hip_atomic_load(flags + (int64_t)i * stride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= want;
-        if (__all(ok)) return true;
+__device__ __forceinline__ bool pd_tags_ok(const float4 &v, unsigned e) {
+    return (((__float_as_uint(v.x) ^ e) | (__float_as_uint(v.y) ^ e) | (__float_as_uint(v.z) ^ e) |
+             (__float_as_uint(v.w) ^ e)) & 1u) == 0u;
+}
+// wave-uniform tagged gather: (re)issues NF sc1 loads per lane until every tag of every lane carries `want`
+// (offsets PD_OOB read zeros and count as valid).  While the data is not there yet the wave polls ONE granule per
+// lane at most (`probe`: a granule of each producer the wave depends on, PD_OOB for lanes that need not look) --
+// hundreds of workgroups re-reading their whole 20-40 KB operand every spin kept the fabric busy enough to delay
+// the very stores they wait for.  The probe is only a hint: the full gather checks every tag and retries.
+// On a timeout sets the abort word and the sticky error.
+template <int NF>
+__device__ __forceinline__ void pd_gather(float4 (&v)[NF], __amdgpu_buffer_rsrc_t r, const int (&off)[NF], unsigned want,
+                                          int probe, int *s_abort, unsigned *err) {
+    int spins = 0;
+    for (;; ++spins) {
+        const float4 t = pd_ld4_sc1(r, probe);
+        if (__all(pd_tags_ok(t, want) | (probe == PD_OOB)) || spins >= PD_SPIN_LIMIT) break;
         __builtin_amdgcn_s_sleep(1);
     }
-    return false;
-}
-// 16 x 16 tile product with the A rows read through sc1 buffer loads (data another workgroup wrote
-// in this launch) and the B rows (weights) through plain loads; K % 4 == 0.  Same k split over waves
-// and lanes as tile16_seg.
-__device__ __forceinline__ void pd_tile16_seg(Tile16Acc &acc, __amdgpu_buffer_rsrc_t ra, int row_byte_off,
-                                              const float *wrow, int K, const float *safe) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
-    const int slots = nw * 4;
-    int kq = (K + slots - 1) / slots;
-    kq = (kq + 3) & ~3;
-    const int kb = (wave * 4 + (lane >> 4)) * kq;
-    const int ke = min(K, kb + kq);
-#pragma unroll 4
-    for (int u = 0; u < kq; u += 4) {
-        const int k = kb + u;
-        const float4 a = pd_ld4_sc1(ra, (row_byte_off >= 0 && k < ke) ? row_byte_off + 4 * k : PD_OOB);
-        const float4 b = t16_load_fast(wrow, k, ke, safe);
-        acc.a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b.x, acc.a0, 0, 0, 0);
-        acc.a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b.y, acc.a1, 0, 0, 0);
-        acc.a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b.z, acc.a0, 0, 0, 0);
-        acc.a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b.w, acc.a1, 0, 0, 0);
+    for (;; ++spins) {
+#pragma unroll
+        for (int f = 0; f < NF; ++f) v[f] = pd_ld4_sc1(r, off[f]);
+        __builtin_amdgcn_sched_barrier(0);
+        bool ok = true;
+#pragma unroll
+        for (int f = 0; f < NF; ++f) ok = ok & (pd_tags_ok(v[f], want) | (off[f] == PD_OOB));
+        if (__all(ok)) return;
+        if (spins >= PD_SPIN_LIMIT) {
+            if ((threadIdx.x & 63) == 0) {
+                *s_abort = 1;
+                __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            return;
+        }
+        __builtin_amdgcn_s_sleep(1);
     }
 }
 
-#define PD_WAIT(cond)                                                                                   \
-    do {                                                                                                \
-        if (wave == 0) {                                                                                \
-            if (!(cond) && lane == 0) {                                                                 \
-                *s_abort = 1;                                                                           \
-                __hip_atomic_store(p.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);              \
-            }                                                                                           \
-        }                                                                                               \
-        __syncthreads();                                                                                \
-        if (*s_abort) return;                                                                           \
-    } while (0)
-#define PD_PUBLISH(flagptr, val)                                                                        \
-    do {                                                                                                \
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                \
-        __syncthreads();                                                                                \
-        if (tid == 0) __hip_atomic_store((flagptr), (unsigned)(val), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); \
-    } while (0)
-
-static size_t attdec_persist_smem(int A, int T) {
-    const int A16 = (A + 15) & ~15, Tp = (T + 3) & ~3;
-    return sizeof(float) * (size_t)(A16 * 14 + TT * 12 + ((TT + KW + 3) & ~3) + NCH * KW + E2P * 64 + 2 * Tp + 4096 +
-                                    T16_MAXW * 16 * 17 + 64);
+static size_t attdec_persist_smem(int Tal) {
+    const int A16 = PD_AL;
+    return sizeof(float) * (size_t)(A16 * 14 + 2 * TT * 12 + ((TT + KW + 3) & ~3) + NCH * KW + 2 * 64 + 2 * Tal + 2048 +
+                                    2 * PD_WAVES * 16 * 17 + 16 * 17 + 32 + 16);
 }
 
 __global__ __launch_bounds__(PD_THREADS) void attdec_fwd_persist_kernel(PDParams p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const asr_attdec_fwd_args &a = p.a;
     const int B = a.B, T = a.T, E = a.E, Hd = a.Hd, L = a.L, V = a.V, A = 2 * Hd;
-    const int NTILE = p.NTILE, MTB = p.MTB, NJ = p.NJ, NSP = p.NSP, EC = p.EC;
-    const int w = blockIdx.x, nWG = gridDim.x;
+    const int NTILE = p.NTILE, MTB = p.MTB, EC = p.EC, A16 = p.A16, Tp = p.Tp, Tal = p.Tal;
+    const int w = blockIdx.x;
     const int b = w / NTILE, k = w - b * NTILE, t0 = k * TT;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, wave = tid >> 6;
     const int len = min(a.lengths[b], T);
-    const int A16 = round16(A);
     E2Smem m;
-    m.sp = smem;
-    m.wfe = m.sp + A16;
-    m.wee = m.wfe + A16 * 12;
-    m.Fs = m.wee + A16;               // [TT][12]
-    m.aw = m.Fs + TT * 12;            // [TT + KW]
-    m.cw = m.aw + round4(TT + KW);    // [NCH*KW]
-    m.red = m.cw + NCH * KW;          // [E2P][64]
-    float *al = m.red + E2P * 64;     // [2][Tp] alpha of the previous / current step
-    float *cred = al + 2 * p.Tp;      // [1024 / (EC/4)][EC] context partial sums
-    float (*red16)[16][17] = reinterpret_cast<float (*)[16][17]>(cred + 4096);
-    float *sred = cred + 4096 + T16_MAXW * 16 * 17;     // [32]
+    m.sp = smem;                         // tables padded to PD_AL units: zeros past A
+    m.wfe = m.sp + PD_AL;
+    m.wee = m.wfe + PD_AL * 12;
+    m.Fs = m.wee + PD_AL;                // [2][TT][12]: the two halves of the taps
+    m.aw = m.Fs + 2 * TT * 12;           // [TT + KW]
+    m.cw = m.aw + round4(TT + KW);       // [NCH*KW]
+    m.red = m.cw + NCH * KW;             // [2][64]
+    float *al = m.red + 2 * 64;          // [2][Tal] alpha of the previous / current step (zero past the length)
+    float *cred = al + 2 * Tal;          // [nfg][EC] context partial sums
+    float (*red16)[16][17] = reinterpret_cast<float (*)[16][17]>(cred + 2048);                        // phase D
+    float (*red16e)[16][17] = reinterpret_cast<float (*)[16][17]>(cred + 2048 + PD_WAVES * 16 * 17);  // phase E
+    float *accS = cred + 2048 + 2 * PD_WAVES * 16 * 17;     // [16][17]: W_ss S_s of this workgroup's cell job
+    float *sred = accS + 16 * 17;                       // [32]
     int *s_abort = reinterpret_cast<int *>(sred + 32);
+    float *wsum = sred + 34;
 
-    unsigned *F_e = p.flags, *F_g = F_e + B * NTILE, *F_S = F_g + B * NTILE, *F_sp = F_S + NJ * MTB;
     const int64_t BH = (int64_t)B * Hd, BT = (int64_t)B * T, BA = (int64_t)B * A, BE = (int64_t)B * E;
-    __amdgpu_buffer_rsrc_t rS = __builtin_amdgcn_make_buffer_rsrc(a.S, 0, (int)((L + 1) * BH * 4), 0x00020000);
-    __amdgpu_buffer_rsrc_t rG = __builtin_amdgcn_make_buffer_rsrc(a.g, 0, (int)(L * BE * 4), 0x00020000);
-    __amdgpu_buffer_rsrc_t rP = __builtin_amdgcn_make_buffer_rsrc(a.sproj, 0, (int)(L * BA * 4), 0x00020000);
+    __amdgpu_buffer_rsrc_t rX = __builtin_amdgcn_make_buffer_rsrc(p.xch, 0, p.xch_bytes, 0x00020000);
 
     // tables that stay in LDS for all L steps
-    for (int i = tid; i < A16 * 13; i += PD_THREADS) m.wfe[i] = p.tab[i];
+    constexpr float K2L = 2.88539008177792681472f;     // 2 log2(e): tanh(x) = 1 - 2 / (1 + 2^(K2L x))
+    for (int i = tid; i < PD_AL * 12; i += PD_THREADS) m.wfe[i] = i < A16 * 12 ? p.tab[i] * K2L : 0.f;
+    for (int i = tid; i < PD_AL; i += PD_THREADS) m.wee[i] = i < A16 ? p.tab[A16 * 12 + i] : 0.f;
     for (int i = tid; i < NCH * KW; i += PD_THREADS) m.cw[i] = a.conv_w[i];
-    for (int i = tid; i < A16; i += PD_THREADS) m.sp[i] = 0.f;
+    for (int i = tid; i < PD_AL; i += PD_THREADS) m.sp[i] = 0.f;
+    for (int i = tid; i < 2 * Tal; i += PD_THREADS) al[i] = 0.f;
+    if (wave == 0) {    // sum of w_ee over the attention units (padded entries are zero)
+        float v = 0.f;
+        for (int i = tid; i < A16; i += 64) v += p.tab[A16 * 12 + i];
+        v = wave_sum(v);
+        if (tid == 0) *wsum = v;
+    }
+    for (int i = tid; i < 16 * 17; i += PD_THREADS) accS[i] = 0.f;
     if (tid == 0) *s_abort = 0;
+
+    // Index arithmetic is re-derived from an OPAQUE copy of the thread id at the top of every phase: whatever the
+    // compiler can prove invariant in s it hoists and keeps live across the whole step loop, and with 160 registers
+    // of resident data per lane there is no room for that.
+    const int nrows = max(0, min(TT, len - t0));
+    const int MT = A16 / 16;
+    const int ncg = EC / 4, nfg = p.nfg;
+    const int c0 = k * EC;
+    // ---- energy role (as energy_fwd2_kernel): 4 frame tiles x 2 parts of the attention dimension
+    float4 phr[PD_MTP];
+    {
+        const int lane = tid & 63, q = lane >> 4, col = lane & 15, tt = wave & 3, part = wave >> 2;
+        const int tl = 16 * tt + col;
+        const int mt0 = part * PD_MTP, mt1 = min(MT, mt0 + PD_MTP);
+        const float *PHrow = a.PH + ((int64_t)b * T + t0 + tl) * A;
+#pragma unroll
+        for (int j = 0; j < PD_MTP; ++j)
+        {
+            const float4 v = e2_load_ph(PHrow, tl < nrows && mt0 + j < mt1, 16 * (mt0 + j) + 4 * q, A, a.PH);
+            phr[j] = make_float4(v.x * K2L, v.y * K2L, v.z * K2L, v.w * K2L);
+        }
+    }
+    // ---- context role: column chunk k of hbatch[b], frames fg + nfg i
+    float4 hreg[PD_HF];
+    {
+        const int cg = tid % ncg, fg = tid / ncg;
+        const bool cact = fg < nfg && c0 + 4 * cg < E;
+        const float *hb = a.hbatch + (int64_t)b * T * E + c0 + 4 * cg;
+#pragma unroll
+        for (int i = 0; i < PD_HF; ++i) {
+            const int t = fg + nfg * i;
+            const bool ok = cact && t < len;
+            const float4 v = ld4(ok ? hb + (int64_t)t * E : a.hbatch);
+            const unsigned mk = ok ? 0xffffffffu : 0u;
+            hreg[i] = make_float4(__uint_as_float(__float_as_uint(v.x) & mk), __uint_as_float(__float_as_uint(v.y) & mk),
+                                  __uint_as_float(__float_as_uint(v.z) & mk), __uint_as_float(__float_as_uint(v.w) & mk));
+        }
+    }
+    // ---- job role: one 16 x 16 tile job per workgroup at most (the host checks)
+    const int ncell = p.NJ * MTB, nsp = p.NSP * MTB;
+    const bool is_cell = w < ncell, is_sp = !is_cell && w < ncell + nsp;
+    const int jw = is_cell ? w : w - ncell;
+    const int jt = jw / MTB, jb0 = 16 * (jw - jt * MTB);     // tile index along units / attention units, first batch row
+    int kqE = (E + 31) / 32, kqH = (Hd + 31) / 32;
+    kqE = (kqE + 3) & ~3;
+    kqH = (kqH + 3) & ~3;
+    float c_reg = 0.f;        // cell state of the owner threads (16 rows x 4 units on threads 0..63)
     __syncthreads();
 
-    // energy roles (as energy_fwd2_kernel)
-    const int q = lane >> 4, col = lane & 15;
-    const int tt = wave & 3, part = wave >> 2;
-    const int tl = 16 * tt + col;
-    const int nrows = max(0, min(TT, len - t0));
-    const bool rowok = tl < nrows;
-    const float *PHrow = a.PH + ((int64_t)b * T + t0 + tl) * A;
-    const int MT = A16 / 16, MTP = (MT + E2P - 1) / E2P;
-    const int mt0 = part * MTP, mt1 = min(MT, mt0 + MTP);
-    const int nact = (len + TT - 1) / TT;       // tiles of this utterance that hold frames
-    const float *hb = a.hbatch + (int64_t)b * T * E;
-
     for (int s = 0; s < L; ++s) {
-        float *al_cur = al + (s & 1) * p.Tp;
-        const float *al_prev = al + ((s & 1) ^ 1) * p.Tp;
-        float *eb = p.ebuf + (int64_t)(s & 1) * BT + (int64_t)b * T;
+        const int slot = s & 1, pslot = slot ^ 1;
+        const unsigned ep = (unsigned)((s >> 1) & 1), pep = (unsigned)(((s - 1) >> 1) & 1);
+        float *al_cur = al + slot * Tal;
+        const float *al_prev = al + pslot * Tal;
         PD_STAMP(0);
-        // ---- A. this utterance's state projection (edge P)
-        if (s > 0) {
-            PD_WAIT(pd_poll(F_sp + b / 16, NSP, MTB, (unsigned)s));
-            if (4 * tid < A) {
-                const float4 v = pd_ld4_sc1(rP, (int)((((int64_t)s * B + b) * A + 4 * tid) * 4));
-                *reinterpret_cast<float4 *>(m.sp + 4 * tid) = v;
+        // embedding row + bias of this step's label for the cell owners: a dependent pair of loads (label, then
+        // its row), issued here so that it is not in front of the context gather of phase D
+        float eb[4] = {0.f, 0.f, 0.f, 0.f};
+        if (is_cell) {
+            const int tid = pd_opaque((int)threadIdx.x);
+            const int ob = jb0 + (tid >> 2), oj = 4 * jt + (tid & 3);
+            if (tid < 64 && ob < B && oj < Hd) {
+                int64_t y = a.targets[(int64_t)ob * L + s];
+                y = y < 0 ? 0 : (y >= V ? V - 1 : y);
+#pragma unroll
+                for (int g = 0; g < 4; ++g) eb[g] = a.Emb[y * 4 * Hd + g * Hd + oj] + a.b_gs[g * Hd + oj];
             }
         }
+        // ---- A. this utterance's state projection (edge P), the alignment window of the convolution
+        if (nrows > 0) {
+            const int tid = pd_opaque((int)threadIdx.x);
+            if (s > 0 && (tid >> 6) * 256 < A) {          // wave-uniform: waves that hold a granule
+                const int off[1] = {4 * tid < A ? ((pslot * B + b) * A16 + 4 * tid) * 4 : PD_OOB};
+                float4 v[1];
+                pd_gather<1>(v, rX, off, pep, PD_OOB, s_abort, p.err);
+                if (4 * tid < A)
+                    *reinterpret_cast<float4 *>(m.sp + 4 * tid) = make_float4(v[0].x * K2L, v[0].y * K2L, v[0].z * K2L, v[0].w * K2L);
+            }
+            for (int i = tid; i < TT + KW; i += PD_THREADS) {
+                const int t = t0 - PADW + i;
+                m.aw[i] = (t >= 0 && t < T) ? al_prev[t] : 0.f;
+            }
+        }
+        __syncthreads();
+        if (*s_abort) return;
         PD_STAMP(1);
         // ---- B. energies of this workgroup's 64 frames
-        float *Fout = a.Fc + (((int64_t)s * B + b) * T + t0) * NCH;
         if (nrows > 0) {
-            float4 ph[E2PF];
+            const int tid = pd_opaque((int)threadIdx.x);
+            const int lane = tid & 63, wave = tid >> 6, q = lane >> 4, col = lane & 15, tt = wave & 3, part = wave >> 2;
+            const int tl = 16 * tt + col;
+            const int mt0 = part * PD_MTP;
+            {   // conv features as a Toeplitz product, the 25 k-steps of the taps split over the two parts
+                f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};     // two chains: MFMA latency
+                const float *arow = m.aw + 16 * tt + col + q;
+                const float *brow = m.cw + (col < NCH ? col : 0) * KW + q;
+                const int ks0 = part ? 13 : 0;
 #pragma unroll
-            for (int jx = 0; jx < E2PF; ++jx)
-                ph[jx] = e2_load_ph(PHrow, rowok && mt0 + jx < mt1, 16 * (mt0 + jx) + 4 * q, A, a.PH);
-            if (s > 0) {
-                for (int i = tid; i < TT + KW; i += PD_THREADS) {
-                    const int t = t0 - PADW + i;
-                    m.aw[i] = (t >= 0 && t < T) ? al_prev[t] : 0.f;
+                for (int u = 0; u < 6; ++u) {
+                    const int ks = ks0 + 2 * u;
+                    const float b0 = col < NCH ? brow[4 * ks] : 0.f, b1 = col < NCH ? brow[4 * ks + 4] : 0.f;
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(arow[4 * ks], b0, acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(arow[4 * ks + 4], b1, acc1, 0, 0, 0);
                 }
-            }
-            __syncthreads();
-            if (wave < 4) {
-                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-                if (s > 0) {
-                    const float *arow = m.aw + 16 * wave + col + q;
-                    const float *brow = m.cw + (col < NCH ? col : 0) * KW + q;
-#pragma unroll 5
-                    for (int ks = 0; ks < KW / 4; ++ks) {
-                        const float bv = col < NCH ? brow[4 * ks] : 0.f;
-                        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(arow[4 * ks], bv, acc, 0, 0, 0);
-                    }
+                if (!part) {
+                    const float b0 = col < NCH ? brow[4 * 12] : 0.f;
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(arow[4 * 12], b0, acc0, 0, 0, 0);
                 }
                 if (col < 12) {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) m.Fs[(16 * wave + 4 * q + r) * 12 + col] = acc[r];
+                    for (int r = 0; r < 4; ++r) m.Fs[part * TT * 12 + (16 * tt + 4 * q + r) * 12 + col] = acc0[r] + acc1[r];
                 }
             }
             __syncthreads();
-            {
-                const int n = min(TT, T - t0) * NCH;
-                for (int i = tid; i < n; i += PD_THREADS) Fout[i] = m.Fs[(i / NCH) * 12 + (i % NCH)];
-            }
             float fB[3];
 #pragma unroll
-            for (int ks = 0; ks < 3; ++ks) fB[ks] = m.Fs[tl * 12 + 4 * ks + q];
-            float e = 0.f;
-            for (int mc = mt0; mc < mt1; mc += E2PF) {
-                if (mc != mt0) {
+            for (int ks = 0; ks < 3; ++ks) fB[ks] = m.Fs[tl * 12 + 4 * ks + q] + m.Fs[TT * 12 + tl * 12 + 4 * ks + q];
+            // PH (registers), sproj and W_fe (LDS) carry the factor 2 log2(e), so the MFMA result is the argument of
+            // 2^x directly; sum_a w_a tanh(x_a) = sum_a w_a - 2 sum_a w_a / (1 + e^{2 x_a}): one FMA per element
+            // No bounds: tiles past A read zero tables (w = 0) and zero PH.  Two tiles per round, the LDS operands of the
+            // next round fetched before this round's arithmetic: two independent MFMA chains, eight independent 2^x / 1/x.
+            struct PDTile { float4 s4, w4; float a0, a1, a2; };
+            auto ldt = [&](int mt) {
+                PDTile t;
+                t.s4 = *reinterpret_cast<const float4 *>(m.sp + 16 * mt + 4 * q);
+                const float *wr = m.wfe + (16 * mt + col) * 12 + q;
+                t.a0 = wr[0]; t.a1 = wr[4]; t.a2 = wr[8];
+                t.w4 = *reinterpret_cast<const float4 *>(m.wee + 16 * mt + 4 * q);
+                return t;
+            };
+            PDTile c0 = ldt(mt0), c1 = ldt(mt0 + 1);
+            float e = 0.f, e1 = 0.f;
 #pragma unroll
-                    for (int jx = 0; jx < E2PF; ++jx)
-                        ph[jx] = e2_load_ph(PHrow, rowok && mc + jx < mt1, 16 * (mc + jx) + 4 * q, A, a.PH);
-                }
+            for (int j = 0; j < PD_MTP; j += 2) {
+                PDTile n0 = c0, n1 = c1;
+                if (j + 2 < PD_MTP) { n0 = ldt(mt0 + j + 2); n1 = ldt(mt0 + j + 3); }
+                f32x4 x0 = {phr[j].x + c0.s4.x, phr[j].y + c0.s4.y, phr[j].z + c0.s4.z, phr[j].w + c0.s4.w};
+                f32x4 x1 = {phr[j + 1].x + c1.s4.x, phr[j + 1].y + c1.s4.y, phr[j + 1].z + c1.s4.z, phr[j + 1].w + c1.s4.w};
+                x0 = __builtin_amdgcn_mfma_f32_16x16x4f32(c0.a0, fB[0], x0, 0, 0, 0);
+                x1 = __builtin_amdgcn_mfma_f32_16x16x4f32(c1.a0, fB[0], x1, 0, 0, 0);
+                x0 = __builtin_amdgcn_mfma_f32_16x16x4f32(c0.a1, fB[1], x0, 0, 0, 0);
+                x1 = __builtin_amdgcn_mfma_f32_16x16x4f32(c1.a1, fB[1], x1, 0, 0, 0);
+                x0 = __builtin_amdgcn_mfma_f32_16x16x4f32(c0.a2, fB[2], x0, 0, 0, 0);
+                x1 = __builtin_amdgcn_mfma_f32_16x16x4f32(c1.a2, fB[2], x1, 0, 0, 0);
+                float t[8];
 #pragma unroll
-                for (int jx = 0; jx < E2PF; ++jx) {
-                    const int mt = mc + jx;
-                    if (mt < mt1) {   // uniform
-                        const f32x4 acc = e2_pre(m, mt, q, col, ph[jx], fB);
-                        const float4 w4 = *reinterpret_cast<const float4 *>(m.wee + 16 * mt + 4 * q);
-                        e += w4.x * tanh_f(acc[0]) + w4.y * tanh_f(acc[1]) + w4.z * tanh_f(acc[2]) + w4.w * tanh_f(acc[3]);
-                    }
-                }
+                for (int r = 0; r < 4; ++r) { t[r] = __builtin_amdgcn_exp2f(x0[r]); t[4 + r] = __builtin_amdgcn_exp2f(x1[r]); }
+#pragma unroll
+                for (int r = 0; r < 8; ++r) t[r] = __builtin_amdgcn_rcpf(1.0f + t[r]);
+                e += c0.w4.x * t[0]; e1 += c1.w4.x * t[4];
+                e += c0.w4.y * t[1]; e1 += c1.w4.y * t[5];
+                e += c0.w4.z * t[2]; e1 += c1.w4.z * t[6];
+                e += c0.w4.w * t[3]; e1 += c1.w4.w * t[7];
+                c0 = n0; c1 = n1;
             }
+            e += e1;
             e += __shfl_xor(e, 16, 64);
             e += __shfl_xor(e, 32, 64);
             if (q == 0) m.red[part * 64 + tl] = e;
             __syncthreads();
-            if (tid < nrows) {
-                float v = 0.f;
-#pragma unroll
-                for (int pp = 0; pp < E2P; ++pp) v += m.red[pp * 64 + tid];
-                pd_st_sc1(eb + t0 + tid, v);
+            if (tid < 16 && 4 * tid < nrows) {
+                const float4 r0 = *reinterpret_cast<const float4 *>(m.red + 4 * tid);
+                const float4 r1 = *reinterpret_cast<const float4 *>(m.red + 64 + 4 * tid);
+                const float ws_ = *wsum;
+                pd_st4_tag(rX, (p.o_e + (slot * B + b) * Tp + t0 + 4 * tid) * 4,
+                           make_float4(ws_ - 2.0f * (r0.x + r1.x), ws_ - 2.0f * (r0.y + r1.y), ws_ - 2.0f * (r0.z + r1.z),
+                                       ws_ - 2.0f * (r0.w + r1.w)), ep);
+            }
+            // saved conv features: behind the hand-off store, nothing in the launch reads them
+            float *Fout = a.Fc + (((int64_t)s * B + b) * T + t0) * NCH;
+            const int n = min(TT, T - t0) * NCH;
+            for (int i = tid; i < n; i += PD_THREADS) {
+                const int r = i / NCH, c = i - r * NCH;
+                Fout[i] = m.Fs[r * 12 + c] + m.Fs[TT * 12 + r * 12 + c];
             }
         } else if (t0 < T) {
+            const int tid = pd_opaque((int)threadIdx.x);
+            float *Fout = a.Fc + (((int64_t)s * B + b) * T + t0) * NCH;
             const int n = min(TT, T - t0) * NCH;
             for (int i = tid; i < n; i += PD_THREADS) Fout[i] = 0.f;
         }
         PD_STAMP(2);
-        PD_PUBLISH(F_e + b * NTILE + k, s + 1);
         // ---- C. softmax over the utterance (every workgroup of b for itself), context chunk k
-        PD_WAIT(pd_poll(F_e + b * NTILE, nact, 1, (unsigned)(s + 1)));
-        PD_STAMP(3);
         {
-            float mx = -INFINITY;
-            for (int t = tid; t < len; t += PD_THREADS) {
-                const float v = pd_ld_sc1(eb + t);
-                al_cur[t] = v;
-                mx = fmaxf(mx, v);
+            const int tid = pd_opaque((int)threadIdx.x);
+            const int lane = tid & 63, wave = tid >> 6;
+            const int ng = (len + 3) >> 2;
+            float4 ev = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+            if (wave * 64 < ng) {      // wave-uniform
+                const int off[1] = {tid < ng ? (p.o_e + (slot * B + b) * Tp + 4 * tid) * 4 : PD_OOB};
+                float4 v[1];
+                pd_gather<1>(v, rX, off, ep, PD_OOB, s_abort, p.err);
+                if (tid < ng) {
+                    ev.x = v[0].x;
+                    if (4 * tid + 1 < len) ev.y = v[0].y;
+                    if (4 * tid + 2 < len) ev.z = v[0].z;
+                    if (4 * tid + 3 < len) ev.w = v[0].w;
+                }
             }
-            mx = wave_max(mx);
+            PD_STAMP(3);
+            float mx = wave_max(fmaxf(fmaxf(ev.x, ev.y), fmaxf(ev.z, ev.w)));
             if (lane == 0) sred[wave] = mx;
             __syncthreads();
+            if (*s_abort) return;
             mx = sred[0];
 #pragma unroll
-            for (int i = 1; i < E2W; ++i) mx = fmaxf(mx, sred[i]);
-            float sum = 0.f;
-            for (int t = tid; t < len; t += PD_THREADS) {
-                const float pe = fast_exp(al_cur[t] - mx);
-                al_cur[t] = pe;
-                sum += pe;
-            }
-            sum = wave_sum(sum);
-            if (lane == 0) sred[16 + wave] = sum;
+            for (int i = 1; i < PD_WAVES; ++i) mx = fmaxf(mx, sred[i]);
+            float4 pe = make_float4(fast_exp(ev.x - mx), fast_exp(ev.y - mx), fast_exp(ev.z - mx), fast_exp(ev.w - mx));
+            float sum = wave_sum((pe.x + pe.y) + (pe.z + pe.w));
+            if (lane == 0) sred[8 + wave] = sum;
             __syncthreads();
             sum = 0.f;
 #pragma unroll
-            for (int i = 0; i < E2W; ++i) sum += sred[16 + i];
+            for (int i = 0; i < PD_WAVES; ++i) sum += sred[8 + i];
             const float inv = 1.0f / sum;
-            float *alpha_s = a.alpha + (int64_t)s * BT + (int64_t)b * T;
-            for (int t = tid; t < T; t += PD_THREADS) {
-                const float av = t < len ? al_cur[t] * inv : 0.f;
-                al_cur[t] = av;
-                if (k == 0) alpha_s[t] = av;
+            pe.x *= inv; pe.y *= inv; pe.z *= inv; pe.w *= inv;
+            if (tid < ng) *reinterpret_cast<float4 *>(al_cur + 4 * tid) = pe;
+            {   // this tile's 64 frames of the saved alignment (zeros past the length)
+                float *alpha_s = a.alpha + (int64_t)s * BT + (int64_t)b * T;
+                const int t = 4 * tid;
+                if (t >= t0 && t < t0 + TT && t < T) {
+                    if ((T & 3) == 0) {
+                        *reinterpret_cast<float4 *>(alpha_s + t) = pe;
+                    } else {
+                        alpha_s[t] = pe.x;
+                        if (t + 1 < T) alpha_s[t + 1] = pe.y;
+                        if (t + 2 < T) alpha_s[t + 2] = pe.z;
+                        if (t + 3 < T) alpha_s[t + 3] = pe.w;
+                    }
+                }
             }
             __syncthreads();
-            const int c0 = k * EC, ncol = min(EC, E - c0);
-            const int ncg = EC / 4, nfg = PD_THREADS / ncg;
+        }
+        {
+            const int tid = pd_opaque((int)threadIdx.x);
             const int cg = tid % ncg, fg = tid / ncg;
             if (fg < nfg) {
                 float4 acc = zero4();
-                if (4 * cg < ncol) {
-                    const float *hc = hb + c0 + 4 * cg;
-#pragma unroll 4
-                    for (int t = fg; t < len; t += nfg) {
-                        const float av = al_cur[t];
-                        const float4 h = ld4(hc + (int64_t)t * E);
-                        acc.x += av * h.x; acc.y += av * h.y; acc.z += av * h.z; acc.w += av * h.w;
-                    }
+                const float *ap = al_cur + fg;
+#pragma unroll
+                for (int i = 0; i < PD_HF; ++i) {
+                    const float av = ap[nfg * i];
+                    acc.x += av * hreg[i].x; acc.y += av * hreg[i].y; acc.z += av * hreg[i].z; acc.w += av * hreg[i].w;
                 }
                 *reinterpret_cast<float4 *>(cred + fg * EC + 4 * cg) = acc;
             }
             __syncthreads();
-            if (tid < ncol) {
-                float v = 0.f;
-                for (int f = 0; f < nfg; ++f) v += cred[f * EC + tid];
-                pd_st_sc1(a.g + (int64_t)s * BE + (int64_t)b * E + c0 + tid, v);
+            if (tid < ncg && c0 + 4 * tid < E) {
+                float4 g4 = zero4();
+                for (int f = 0; f < nfg; ++f) {
+                    const float4 v = *reinterpret_cast<const float4 *>(cred + f * EC + 4 * tid);
+                    g4.x += v.x; g4.y += v.y; g4.z += v.z; g4.w += v.w;
+                }
+                pd_st4_tag(rX, (p.o_g + slot * B * E + ((c0 >> 2) + tid) * 4 * B + 4 * b) * 4, g4, ep);
+                *reinterpret_cast<float4 *>(a.g + (int64_t)s * BE + (int64_t)b * E + c0 + 4 * tid) = g4;
             }
         }
         PD_STAMP(4);
-        PD_PUBLISH(F_g + b * NTILE + k, s + 1);
-        // ---- D. cell jobs: 4 hidden units (all four gates) x 16 batch rows
-        for (int j = w; j < NJ * MTB; j += nWG) {
-            const int jt = j / MTB, mt = j - jt * MTB;
-            const int b0 = 16 * mt, j0 = 4 * jt, nr = min(16, B - b0);
-            PD_WAIT(pd_poll(F_g + b0 * NTILE, nr * NTILE, 1, (unsigned)(s + 1)) &&
-                    (s == 0 || pd_poll(F_S + mt, NJ, MTB, (unsigned)s)));
+        // ---- D. cell job: 4 hidden units (all four gates) x 16 batch rows; the W_ss S_s term waits in accS
+#ifndef PD_NO_D
+        if (is_cell) {
+            const int tid = pd_opaque((int)threadIdx.x);
+            const int lane = tid & 63, wave = tid >> 6, q = lane >> 4, ji = lane & 15;
+            const int jrow = jb0 + ji;                 // A row (batch) of this lane
+            const int cu = 4 * jt + (ji & 3);          // B row: gate (ji >> 2) of unit cu
+            const int kbE = (wave * 4 + q) * kqE, keE = min(E, kbE + kqE);
+            const float *wrow_gs = cu < Hd ? a.W_gs + ((int64_t)(ji >> 2) * Hd + cu) * E : nullptr;
+            float4 wv[PD_KF];
+#pragma unroll
+            for (int f = 0; f < PD_KF; ++f) wv[f] = t16_load_fast(wrow_gs, kbE + 4 * f, keE, a.W_gs);
+            const int obi = tid >> 2, oju = tid & 3;
+            const int ob = jb0 + obi, oj = 4 * jt + oju;
+            const bool owner = tid < 64 && ob < B && oj < Hd;
+            int off[PD_KF];
+#pragma unroll
+            for (int f = 0; f < PD_KF; ++f)
+                off[f] = (jrow < B && kbE + 4 * f < keE) ? (p.o_g + slot * B * E + ((kbE >> 2) + f) * 4 * B + 4 * jrow) * 4 : PD_OOB;
+            float4 av[PD_KF];
+            // no probe: the other producers finish with this workgroup's own context chunk, the wait is a spin or two
+            pd_gather<PD_KF>(av, rX, off, ep, PD_OOB, s_abort, p.err);
             PD_STAMP(5);
-            {
-                const int i = lane & 15, bb = b0 + i;
-                const int gate = i >> 2, jj = j0 + (i & 3);
-                const int64_t wr = (int64_t)gate * Hd + jj;
-                Tile16Acc acc;
-                tile16_init(acc);
-                if (s > 0)
-                    pd_tile16_seg(acc, rS, bb < B ? (int)((((int64_t)s * B + bb) * Hd) * 4) : -1,
-                                  jj < Hd ? a.W_ss + wr * Hd : nullptr, Hd, a.W_ss);
-                pd_tile16_seg(acc, rG, bb < B ? (int)((((int64_t)s * B + bb) * E) * 4) : -1,
-                              jj < Hd ? a.W_gs + wr * E : nullptr, E, a.W_gs);
-                tile16_reduce(acc, red16);
+            Tile16Acc acc;
+            tile16_init(acc);
+#pragma unroll
+            for (int f = 0; f < PD_KF; ++f) {
+                acc.a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[f].x, wv[f].x, acc.a0, 0, 0, 0);
+                acc.a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[f].y, wv[f].y, acc.a1, 0, 0, 0);
+                acc.a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[f].z, wv[f].z, acc.a0, 0, 0, 0);
+                acc.a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[f].w, wv[f].w, acc.a1, 0, 0, 0);
             }
+            tile16_reduce(acc, red16);
+            if (*s_abort) return;
             if (tid < 64) {
-                const int bi = tid >> 2, ju = tid & 3;
-                const int bb = b0 + bi, jj = j0 + ju;
-                if (bb < B && jj < Hd) {
-                    int64_t y = a.targets[(int64_t)bb * L + s];
-                    y = y < 0 ? 0 : (y >= V ? V - 1 : y);
+                float hval = 0.f;
+                if (owner) {
                     float pre[4];
 #pragma unroll
                     for (int g = 0; g < 4; ++g)
-                        pre[g] = tile16_get(red16, bi, g * 4 + ju) + a.Emb[y * 4 * Hd + g * Hd + jj] + a.b_gs[g * Hd + jj];
-                    const float ig = sigmoid_tanh_form(pre[0]), fg = sigmoid_tanh_form(pre[1]);
+                        pre[g] = tile16_get(red16, obi, g * 4 + oju) + accS[obi * 17 + g * 4 + oju] + eb[g];
+                    const float ig = sigmoid_tanh_form(pre[0]), fgt = sigmoid_tanh_form(pre[1]);
                     const float gg = tanh_f(pre[2]), og = sigmoid_tanh_form(pre[3]);
-                    const float cprev = a.C[(int64_t)s * BH + (int64_t)bb * Hd + jj];
-                    const float c = fg * cprev + ig * gg;
-                    float *gd = a.gates + (int64_t)s * 4 * BH + (int64_t)bb * 4 * Hd;
-                    gd[0 * Hd + jj] = ig; gd[1 * Hd + jj] = fg; gd[2 * Hd + jj] = gg; gd[3 * Hd + jj] = og;
-                    a.C[(int64_t)(s + 1) * BH + (int64_t)bb * Hd + jj] = c;
-                    pd_st_sc1(a.S + (int64_t)(s + 1) * BH + (int64_t)bb * Hd + jj, og * tanh_f(c));
+                    c_reg = fgt * c_reg + ig * gg;
+                    hval = og * tanh_f(c_reg);
+                    float *gd = a.gates + (int64_t)s * 4 * BH + (int64_t)ob * 4 * Hd;
+                    gd[0 * Hd + oj] = ig; gd[1 * Hd + oj] = fgt; gd[2 * Hd + oj] = gg; gd[3 * Hd + oj] = og;
+                    a.C[(int64_t)(s + 1) * BH + (int64_t)ob * Hd + oj] = c_reg;
+                    a.S[(int64_t)(s + 1) * BH + (int64_t)ob * Hd + oj] = hval;
                 }
+                // the 4 units of a batch row sit on 4 adjacent lanes: one 16-byte tagged store per row
+                const float h1 = ASR_DPP(hval, 0x55), h2 = ASR_DPP(hval, 0xAA), h3 = ASR_DPP(hval, 0xFF);
+                if (oju == 0 && ob < B && 4 * jt < Hd)
+                    pd_st4_tag(rX, (p.o_S + slot * B * Hd + jt * 4 * B + 4 * ob) * 4, make_float4(hval, h1, h2, h3), ep);
             }
             PD_STAMP(6);
-            PD_PUBLISH(F_S + j, s + 1);
         }
-        // ---- E. state-projection jobs for the next step: 16 attention units x 16 batch rows
-        if (s + 1 < L) {
-            int jf = w - (NJ * MTB) % nWG;
-            if (jf < 0) jf += nWG;
-            for (int j = jf; j < NSP * MTB; j += nWG) {
-                const int nt = j / MTB, mt = j - nt * MTB;
-                const int n0 = 16 * nt, b0 = 16 * mt;
-                PD_WAIT(pd_poll(F_S + mt, NJ, MTB, (unsigned)(s + 1)));
-                PD_STAMP(7);
-                {
-                    const int i = lane & 15;
-                    Tile16Acc acc;
-                    tile16_init(acc);
-                    pd_tile16_seg(acc, rS, b0 + i < B ? (int)((((int64_t)(s + 1) * B + b0 + i) * Hd) * 4) : -1,
-                                  n0 + i < A ? a.W_se + (int64_t)(n0 + i) * Hd : nullptr, Hd, a.W_se);
-                    tile16_reduce(acc, red16);
-                }
-                if (tid < 256) {
-                    const int bi = tid >> 4, ni = tid & 15;
-                    if (b0 + bi < B && n0 + ni < A)
-                        pd_st_sc1(a.sproj + (int64_t)(s + 1) * BA + (int64_t)(b0 + bi) * A + n0 + ni,
-                                  tile16_get(red16, bi, ni));
-                }
-                PD_STAMP(8);
-                PD_PUBLISH(F_sp + j, s + 1);
+#endif
+        // ---- E. products with S_{s+1}: state projection of the next step; W_ss S_{s+1} of the next cell job
+#ifndef PD_NO_E
+        if ((is_cell || is_sp) && s + 1 < L) {
+            const int tid = pd_opaque((int)threadIdx.x);
+            const int lane = tid & 63, wave = tid >> 6, q = lane >> 4, ji = lane & 15;
+            const int jrow = jb0 + ji;
+            const int cu = 4 * jt + (ji & 3);
+            const int kbH = (wave * 4 + q) * kqH, keH = min(Hd, kbH + kqH);
+            // weight row of this lane: cell job -> gate (ji >> 2) of unit cu; state projection -> attention unit 16 jt + ji
+            const float *wrow_S = is_cell ? (cu < Hd ? a.W_ss + ((int64_t)(ji >> 2) * Hd + cu) * Hd : nullptr)
+                                          : (16 * jt + ji < A ? a.W_se + (int64_t)(16 * jt + ji) * Hd : nullptr);
+            constexpr int KFH = 3;         // Hd <= 32 slots x 12
+            float4 wv[KFH];
+#pragma unroll
+            for (int f = 0; f < KFH; ++f) wv[f] = t16_load_fast(wrow_S, kbH + 4 * f, keH, a.W_se);
+            int off[KFH];
+#pragma unroll
+            for (int f = 0; f < KFH; ++f)
+                off[f] = (jrow < B && kbH + 4 * f < keH) ? (p.o_S + slot * B * Hd + ((kbH >> 2) + f) * 4 * B + 4 * jrow) * 4 : PD_OOB;
+            float4 av[KFH];
+            // probe: lanes 0..2 of each k-slot look at one granule of each of the slot's producers
+            pd_gather<KFH>(av, rX, off, ep, ji == 0 ? off[0] : (ji == 1 ? off[1] : (ji == 2 ? off[2] : PD_OOB)), s_abort, p.err);
+            PD_STAMP(7);
+            Tile16Acc acc;
+            tile16_init(acc);
+#pragma unroll
+            for (int f = 0; f < KFH; ++f) {
+                acc.a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[f].x, wv[f].x, acc.a0, 0, 0, 0);
+                acc.a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[f].y, wv[f].y, acc.a1, 0, 0, 0);
+                acc.a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[f].z, wv[f].z, acc.a0, 0, 0, 0);
+                acc.a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[f].w, wv[f].w, acc.a1, 0, 0, 0);
             }
+            tile16_reduce(acc, red16e);
+            if (*s_abort) return;
+            if (is_cell) {
+                if (tid < 256) accS[(tid >> 4) * 17 + (tid & 15)] = tile16_get(red16e, tid >> 4, tid & 15);
+            } else if (tid < 64) {
+                const int bi = tid >> 2, n4 = (tid & 3) * 4;
+                const int bb = jb0 + bi, n0 = 16 * jt + n4;
+                if (bb < B && n0 < A) {
+                    const float4 v = make_float4(tile16_get(red16e, bi, n4), tile16_get(red16e, bi, n4 + 1),
+                                                 tile16_get(red16e, bi, n4 + 2), tile16_get(red16e, bi, n4 + 3));
+                    pd_st4_tag(rX, ((slot * B + bb) * A16 + n0) * 4, v, ep);
+                    *reinterpret_cast<float4 *>(a.sproj + (int64_t)(s + 1) * BA + (int64_t)bb * A + n0) = v;
+                }
+            }
+            PD_STAMP(8);
         }
+#endif
         PD_STAMP(9);
     }
 }
 
 
-extern "C" int64_t asr_attdec_ws_floats(int B, int T, int E, int Hd, int L) {
-    (void)E; (void)L;
+// workspace layout (floats): e_buf [round4(B*T)] | 64 | tables [A16*13] | 64 | persistent kernel: exchange area
+// X_sp [2][B][A16] | X_e [2][B][Tp] | X_g [2][B][E] | X_S [2][B][Hd]  (Tp = 64 ceil(T/64)) | 64 | error word | 63
+static int64_t attdec_ws_xch_offset(int B, int T, int Hd) {
     const int64_t A16 = (2 * Hd + 15) & ~15;
-    // e_buf | tables | (persistent kernel) two energy slots, flag words, error word
-    const int64_t nflags = 2 * (int64_t)B * cdiv(T, TT) + (int64_t)(cdiv(Hd, 4) + cdiv(A16, 16)) * cdiv(B, 16);
-    return (int64_t)B * T + 64 + A16 * 13 + 64 + 2 * (int64_t)B * T + 64 + nflags + 64;
+    return (((int64_t)B * T + 3) & ~(int64_t)3) + 64 + A16 * 13 + 64;
+}
+static int64_t attdec_ws_xch_floats(int B, int T, int E, int Hd) {
+    const int64_t A16 = (2 * Hd + 15) & ~15, Tp = (int64_t)cdiv(T, TT) * TT;
+    return 2 * (int64_t)B * (A16 + Tp + E + Hd);
+}
+extern "C" int64_t asr_attdec_ws_floats(int B, int T, int E, int Hd, int L) {
+    (void)L;
+    return attdec_ws_xch_offset(B, T, Hd) + attdec_ws_xch_floats(B, T, E, Hd) + 64 + 64;
 }
 
 // Index (in floats) of the persistent kernel's sticky error word inside the workspace: set when an in-launch
 // wait timed out (the outputs are then garbage); the Python wrapper folds it into the outputs (NaN).
 extern "C" int64_t asr_attdec_err_offset(int B, int T, int E, int Hd, int L) {
-    (void)E; (void)L;
-    const int64_t A16 = (2 * Hd + 15) & ~15;
-    const int64_t nflags = 2 * (int64_t)B * cdiv(T, TT) + (int64_t)(cdiv(Hd, 4) + cdiv(2 * Hd, 16)) * cdiv(B, 16);
-    return (int64_t)B * T + 64 + A16 * 13 + 64 + 2 * (int64_t)B * T + 64 + nflags;
+    (void)L;
+    return attdec_ws_xch_offset(B, T, Hd) + attdec_ws_xch_floats(B, T, E, Hd) + 64;
 }
 
 // diagnostics: a device buffer of B*ceil(T/64) * L * 10 uint64 that the next persistent launches fill with phase
@@ -1165,7 +1311,7 @@ static int run_attdec_fwd(const asr_attdec_fwd_args *a, const GreedyParams *gp, 
     const int64_t BH = (int64_t)B * Hd, BT = (int64_t)B * T, BA = (int64_t)B * A, BE = (int64_t)B * E;
     const int A16p = (A + 15) & ~15;
     float *e_buf = a->ws;
-    float *tab = a->ws + BT + 64;            // padded W_fe / w_ee tables of the v2 energy kernel
+    float *tab = a->ws + ((BT + 3) & ~(int64_t)3) + 64;   // padded W_fe / w_ee tables of the v2 energy kernel
     ASR_CHECK_HIP(hipMemsetAsync(a->S, 0, sizeof(float) * BH, st));
     ASR_CHECK_HIP(hipMemsetAsync(a->C, 0, sizeof(float) * BH, st));
     ASR_CHECK_HIP(hipMemsetAsync(a->sproj, 0, sizeof(float) * BA, st));
@@ -1199,32 +1345,41 @@ static int run_attdec_fwd(const asr_attdec_fwd_args *a, const GreedyParams *gp, 
                 n_cu = 0;
         }
         const int NTILE = cdiv(T, TT), MTB = cdiv(B, 16);
-        const size_t psm = attdec_persist_smem(A, T);
-        const int64_t big = (int64_t)0x7fff0000;
-        if (attdec_persist_on() && !gp && use_v2 && vecH && vecS && vecG && A % 16 == 0 && (int64_t)B * NTILE <= n_cu &&
-            psm <= 150 * 1024 && (L + 1) * BH * 4 < big && L * BE * 4 < big && L * BA * 4 < big) {
+        PDParams p;
+        p.NTILE = NTILE;
+        p.MTB = MTB;
+        p.NJ = cdiv(Hd, 4);
+        p.NSP = cdiv(A, 16);
+        p.EC = ((cdiv(E, NTILE) + 3) / 4) * 4;
+        p.nfg = PD_THREADS / (p.EC / 4);
+        p.A16 = A16p;
+        p.Tp = NTILE * TT;
+        p.Tal = (std::max(p.Tp, p.nfg * PD_HF) + 3) & ~3;
+        const size_t psm = attdec_persist_smem(p.Tal);
+        const int64_t xfl = attdec_ws_xch_floats(B, T, E, Hd);
+        const int64_t nwg = (int64_t)B * NTILE;
+        if (attdec_persist_on() && !gp && use_v2 && vecH && vecS && vecG && A % 16 == 0 && nwg <= n_cu &&
+            (int64_t)(p.NJ + p.NSP) * MTB <= nwg && A16p <= 32 * PD_MTP && E <= 128 * PD_KF && Hd <= 384 &&
+            p.EC / 4 <= PD_THREADS && (int64_t)p.nfg * PD_HF >= T && psm <= 150 * 1024 && xfl * 4 < (int64_t)0x7fff0000 &&
+            al16(a->g) && al16(a->sproj) && al16(a->ws)) {
             static thread_local bool attr3 = false;
             if (!attr3) {
                 ASR_CHECK_HIP(hipFuncSetAttribute((const void *)attdec_fwd_persist_kernel,
                                                   hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
                 attr3 = true;
             }
-            PDParams p;
             p.a = *a;
             p.tab = tab;
-            p.ebuf = tab + (int64_t)A16p * 13 + 64;
-            p.NTILE = NTILE;
-            p.MTB = MTB;
-            p.NJ = cdiv(Hd, 4);
-            p.NSP = cdiv(A, 16);
-            p.EC = ((cdiv(E, NTILE) + 3) / 4) * 4;
-            p.Tp = (T + 3) & ~3;
-            const int64_t nflags = 2 * (int64_t)B * NTILE + (int64_t)(p.NJ + p.NSP) * MTB;
-            p.flags = reinterpret_cast<unsigned *>(p.ebuf + 2 * BT + 64);
-            p.err = p.flags + nflags;
+            p.xch = a->ws + attdec_ws_xch_offset(B, T, Hd);
+            p.o_e = 2 * B * A16p;
+            p.o_g = p.o_e + 2 * B * p.Tp;
+            p.o_S = p.o_g + 2 * B * E;
+            p.xch_bytes = (int)(xfl * 4);
+            p.err = reinterpret_cast<unsigned *>(a->ws + asr_attdec_err_offset(B, T, E, Hd, L));
             p.stamps = g_attdec_stamps;
-            ASR_CHECK_HIP(hipMemsetAsync(p.flags, 0, sizeof(unsigned) * (size_t)(nflags + 1), st));
-            hipLaunchKernelGGL(attdec_fwd_persist_kernel, dim3(B * NTILE), dim3(PD_THREADS), psm, st, p);
+            // every exchanged float starts with the "wrong" epoch tag (LSB = 1)
+            ASR_CHECK_HIP(hipMemsetAsync(p.xch, 0xFF, sizeof(float) * (size_t)xfl, st));
+            hipLaunchKernelGGL(attdec_fwd_persist_kernel, dim3((unsigned)nwg), dim3(PD_THREADS), psm, st, p);
             ASR_CHECK_LAUNCH("attdec_fwd_persist_kernel");
             return ASR_OK;
         }
@@ -1292,7 +1447,7 @@ extern "C" int asr_attdec_step_att(const asr_attdec_fwd_args *a, const float *al
     const int64_t BT = (int64_t)B * T;
     const int A16p = (A + 15) & ~15;
     float *e_buf = a->ws;
-    float *tab = a->ws + BT + 64;
+    float *tab = a->ws + ((BT + 3) & ~(int64_t)3) + 64;
     const int vecPH = al16(a->PH) && A % 4 == 0;
     const size_t esm2 = energy_fwd2_smem(A);
     const bool use_v2 = vecPH && esm2 <= 150 * 1024;

@@ -25,8 +25,6 @@ with torch.no_grad():
     torch.cuda.synchronize()
     lib.asr_attdec_debug_stamps(0)
 s = st.cpu().double() * 0.01      # us (100 MHz)
-names = ["A wait sproj+load", "B energy", "publish e + wait e", "C softmax+ctx", "publish g + wait g,S (cell WGs)",
-         "D cell compute", "publish S + wait S (sproj WGs)", "E sproj compute", "rest of step"]
 steps = slice(5, L - 1)
 tot = (s[:, steps, 9] - s[:, steps, 0])
 print(f"step time (all WGs, steps 5..): mean {tot.mean():.2f} us")
@@ -35,12 +33,29 @@ def seg(i, j, sel=None):
     ok = (s[:, steps, j] > 0) & (s[:, steps, i] > 0)
     if sel is not None:
         ok = ok & sel[:, None]
-    return float(d[ok].mean()) if ok.any() else float("nan"), float(d[ok].max()) if ok.any() else float("nan")
+    return (float(d[ok].mean()), float(d[ok].max())) if ok.any() else (float("nan"), float("nan"))
 wg = torch.arange(NW)
+nt = (T + 63) // 64
+act = ((wg % nt) * 64 < lengths[wg // nt])          # workgroups whose frame tile holds frames
 cellwg = wg < 160
 spwg = (wg >= 160) & (wg < 240)
-for nm, i, j, sel in [(names[0], 0, 1, None), (names[1], 1, 2, None), (names[2], 2, 3, None), (names[3], 3, 4, None),
-                      (names[4], 4, 5, cellwg), (names[5], 5, 6, cellwg), ("publish S .. end of step (cell WGs)", 6, 9, cellwg),
-                      ("publish g .. S ready (sproj WGs)", 4, 7, spwg), (names[7], 7, 8, spwg), ("publish sproj .. end", 8, 9, spwg)]:
-    m, mx = seg(i, j, sel)
-    print(f"  {nm:44s} mean {m:6.2f} us   max {mx:6.2f} us")
+for nm, i, j, sel in [("A wait sproj + window (active tiles)", 0, 1, act), ("B conv + energies + publish e (active)", 1, 2, act),
+                      ("C1 wait e", 2, 3, None), ("C2 softmax + context + publish g", 3, 4, None),
+                      ("D1 weights + wait g (cell WGs)", 4, 5, cellwg), ("D2 cell + publish S (cell WGs)", 5, 6, cellwg),
+                      ("E1 weights + wait S (cell WGs)", 6, 7, cellwg), ("E2 W_ss S product (cell WGs)", 7, 8, cellwg),
+                      ("E1 weights + wait S (sproj WGs)", 4, 7, spwg), ("E2 sproj + publish (sproj WGs)", 7, 8, spwg)]:
+    m_, mx = seg(i, j, sel)
+    print(f"  {nm:44s} mean {m_:6.2f} us   max {mx:6.2f} us")
+# absolute timeline of one step for batch tile 0 (utterances 0..15): stamps relative to the first workgroup's stamp 0
+att = (wg // nt) < 16
+cell0 = cellwg & (wg % 2 == 0)
+sp0 = spwg & ((wg - 160) % 2 == 0)
+print("timeline of batch tile 0, us after the tile's first stamp 0 (min / mean / max over workgroups; mean over steps 5..)")
+ref = s[att][:, steps, 0].min(dim=0).values            # per step
+for nm, i, sel in [("0 step start (attention WGs)", 0, att), ("1 sproj in LDS (active tiles)", 1, att & act),
+                   ("2 e published (active tiles)", 2, att & act), ("3 e gathered", 3, att), ("4 g published", 4, att),
+                   ("5 g gathered (cell jobs)", 5, cell0), ("6 S published (cell jobs)", 6, cell0),
+                   ("7 S gathered (sproj jobs)", 7, sp0), ("8 sproj published (sproj jobs)", 8, sp0),
+                   ("9 step end (attention WGs)", 9, att)]:
+    d = s[sel][:, steps, i] - ref[None, :]
+    print(f"  {nm:36s} {float(d.min(dim=0).values.mean()):6.2f} / {float(d.mean()):6.2f} / {float(d.max(dim=0).values.mean()):6.2f}")
