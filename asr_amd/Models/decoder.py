@@ -133,6 +133,9 @@ class _AttDecFunction(torch.autograd.Function):
                          ws=ws).items():
             setattr(a, k, v.data_ptr())
         check(lib.asr_attdec_bwd(C.byref(a), _stream()))
+        # a timed-out in-launch wait of the persistent loop kernel turns dPH (-> every encoder gradient) into NaN
+        check(lib.asr_poison_if_flag(ws.data_ptr() + 4 * int(lib.asr_attdec_bwd_err_offset(B, T, E, Hd, L)),
+                                     dPH.data_ptr(), _stream()))
         dPH2 = dPH.view(B * T, A)
         h2 = hbatch.view(B * T, E)
         # critical path first: d hbatch = dPH W_he + sum_s alpha_s (x) dg_s  (per utterance:

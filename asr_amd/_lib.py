@@ -127,6 +127,7 @@ SYMBOLS = {
     "asr_attdec_step_att": (C.c_int, [C.POINTER(AttDecFwdArgs), c_f, c_f]),
     "asr_attdec_step_cell": (C.c_int, [C.POINTER(AttDecFwdArgs), c_f]),
     "asr_attdec_bwd_ws_floats": (c_i64, [C.c_int] * 5),
+    "asr_attdec_bwd_err_offset": (c_i64, [C.c_int] * 5),
     "asr_attdec_bwd": (C.c_int, [C.POINTER(AttDecBwdArgs), c_f]),
     # Conformer encoder (csrc/conformer.hip)
     "asr_layernorm_fwd": (C.c_int, [c_f] * 6 + [c_i64, C.c_int, C.c_float, c_f]),

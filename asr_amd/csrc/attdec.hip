@@ -21,6 +21,7 @@
 // full-line global reads and read back transposed, bank-conflict free.
 // HBM/L3 traffic per step: PH once (energy) + hbatch once (ctx) = 2*B*T*A*4 B.
 #include <stdlib.h>
+#include <string.h>
 #include <algorithm>
 
 #include "tile16.cuh"
@@ -2167,9 +2168,524 @@ __global__ __launch_bounds__(128) void dconv_kernel(const float *__restrict__ dF
     }
 }
 
+// ==================================================== persistent backward ==
+// The L-step BPTT loop (dscell, dg, dalpha, energy_bwd above) in ONE launch, same skeleton as the persistent
+// forward: workgroup (b, k) of the grid B x ceil(T/64), 512 threads, one per compute unit, holds in REGISTERS the
+// 64-frame tile k of PH[b] (energy backward, C/D layout of the MFMAs) and of hbatch[b] (dalpha = h . dg: lane
+// (frame, 1/8 of the columns)), so a step streams nothing from HBM but its own saved alpha / conv-feature tile.
+// The M = 32 products are 16 x 16 tile jobs: cell-backward jobs X (16 rows x 16 hidden units) on workgroups
+// [0, NX), context-gradient jobs G (16 rows x 16 columns of E, the K = 4 Hd reduction split in two halves whose
+// partial results the consumer adds) on the next NG.  Per step s = L-1 .. 0 the chain is
+//   dsp_{s+1}            -> X: dS = dsp W_se + [drec_{s+1} W_ss + dyp_{s+1} W_sy], cell backward -> drec_s   (edge R)
+//   drec_s               -> G: dg_s = drec_s W_gs + dyp_s W_gy (two partials)                              (edge G)
+//   dg_s[b]              -> (b, k): dalpha tile = h . dg + conv^T(dF_{s+1}); <alpha, dalpha> partial         (edge D)
+//   8 dot partials       -> (b, k): de, dpre = de w sech^2, dF tile, dsp partial over the tile's frames     (edge P1)
+//   dsp partials of b    -> (b, k): dsp_s[b, chunk k]                                                        (edge P2) -> X
+// Off the chain: the bracketed term of dS (X gathers drec_s right after publishing it and keeps the product in a
+// register until the next step; dyp W_sy and dyp W_gy are hoisted GEMMs Q1, Q2), and conv^T(dF_{s+1}) (computed
+// from the neighbours' published dF tiles while the X and G jobs run; a Toeplitz product on the matrix cores:
+// out[16 a + n] = sum_v x[192 a + v] kf[v - 12 n] over the flattened (frame, channel) window).
+// Hand-offs exactly as in the forward kernel (tagged 16-byte sc1 granules, two parity slots, bounded spins).
+struct PBParams {
+    asr_attdec_bwd_args a;
+    const float *tab;      // padded W_fe / w_ee tables (e2_prep_kernel)
+    const float *Q1;       // (L,B,Hd) dyp W_sy
+    const float *Q2;       // (L,B,E)  dyp W_gy
+    float *xch;            // exchange area: X_dsp | X_drec | X_dgp | X_dot | X_dspp | X_dF
+    unsigned *err;
+    int NTILE, MTB, NJX, NJG, ECG, ECH, A16, Tp;
+    int o_drec, o_dgp, o_dot, o_dspp, o_dF, xch_bytes;
+    unsigned long long *stamps;
+};
+#define PB_XW (163 * 12)          // flattened dF window: frames t0 - 49 .. t0 + 113, 12 floats each
+#define PB_KF (1200 + 2 * 180)    // flattened reversed taps, 180 zeros either side
+#define PB_NKS 345                // k-steps of the Toeplitz product: (180 + 1200) / 4
+
+static size_t attdec_bwd_persist_smem() {
+    return sizeof(float) * (size_t)(PD_AL * 14 + TT * 12 + PD_AL + 4 * TT + (PB_XW + 12) + PB_KF + PD_WAVES * TT +
+                                    4 * PD_AL + 2 * TT * 16 + 2 * PD_WAVES * 16 * 17 + 8 * PD_AL / 8 + 64);
+}
+
+__global__ __launch_bounds__(PD_THREADS) void attdec_bwd_persist_kernel(PBParams p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const asr_attdec_bwd_args &a = p.a;
+    const asr_attdec_fwd_args &f = p.a.f;
+    const int B = f.B, T = f.T, E = f.E, Hd = f.Hd, L = f.L, A = 2 * Hd;
+    const int NTILE = p.NTILE, MTB = p.MTB, ECG = p.ECG, ECH = p.ECH, A16 = p.A16, Tp = p.Tp;
+    const int w = blockIdx.x;
+    const int b = w / NTILE, k = w - b * NTILE, t0 = k * TT;
+    const int tid = threadIdx.x, wave = tid >> 6;
+    const int len = min(f.lengths[b], T);
+    constexpr float K2L = 2.88539008177792681472f;
+    E2Smem m;
+    m.sp = smem;                          // [PD_AL] K2L * sproj_s[b]
+    m.wfe = m.sp + PD_AL;                 // [PD_AL][12] K2L * W_fe
+    m.wee = m.wfe + PD_AL * 12;           // [PD_AL]
+    m.Fs = m.wee + PD_AL;                 // [TT][12] saved conv features of this step
+    float *dgs = m.Fs + TT * 12;          // [8 ECG <= PD_AL] dg_s[b]
+    float *altile = dgs + PD_AL;          // [TT] alpha_s tile
+    float *dcv = altile + TT;             // [TT] conv^T term of dalpha
+    float *detile = dcv + TT;             // [TT]
+    float *pdot = detile + TT;            // [TT]
+    float *xw = pdot + TT;                // [PB_XW + 12]
+    float *kfp = xw + PB_XW + 12;         // [PB_KF]
+    float *dcvw = kfp + PB_KF;            // [PD_WAVES][TT]
+    m.dspl = dcvw + PD_WAVES * TT;        // [4][PD_AL]
+    m.dFl = m.dspl + 4 * PD_AL;           // [2][TT][16]
+    float (*red16)[16][17] = reinterpret_cast<float (*)[16][17]>(m.dFl + 2 * TT * 16);                    // X, G
+    float (*red16b)[16][17] = reinterpret_cast<float (*)[16][17]>(m.dFl + 2 * TT * 16 + PD_WAVES * 16 * 17);  // X2
+    float *rbuf = m.dFl + 2 * TT * 16 + 2 * PD_WAVES * 16 * 17;     // [8][ECH <= PD_AL / 8]
+    float *sred = rbuf + PD_AL;           // [32]
+    int *s_abort = reinterpret_cast<int *>(sred + 32);
+    float *sdot = sred + 34;
+
+    const int64_t BH = (int64_t)B * Hd, BT = (int64_t)B * T, BA = (int64_t)B * A, BE = (int64_t)B * E;
+    __amdgpu_buffer_rsrc_t rX = __builtin_amdgcn_make_buffer_rsrc(p.xch, 0, p.xch_bytes, 0x00020000);
+
+    for (int i = tid; i < PD_AL * 12; i += PD_THREADS) m.wfe[i] = i < A16 * 12 ? p.tab[i] * K2L : 0.f;
+    for (int i = tid; i < PD_AL; i += PD_THREADS) {
+        m.wee[i] = i < A16 ? p.tab[A16 * 12 + i] : 0.f;
+        m.sp[i] = 0.f;
+        dgs[i] = 0.f;
+    }
+    for (int i = tid; i < PB_KF; i += PD_THREADS) {
+        const int v = i - 180, j = v / 12, c = v - 12 * j;
+        kfp[i] = (v >= 0 && v < 1200 && c < NCH) ? f.conv_w[c * KW + (KW - 1 - j)] : 0.f;
+    }
+    for (int i = tid; i < PB_XW + 12; i += PD_THREADS) xw[i] = 0.f;
+    for (int i = tid; i < TT; i += PD_THREADS) dcv[i] = 0.f;
+    if (tid == 0) *s_abort = 0;
+
+    const int nrows = max(0, min(TT, len - t0));
+    const int nact = (len + TT - 1) / TT;          // tiles of this utterance that hold frames
+    const int MT = A16 / 16;
+    // ---- energy role: PH tile, pre-scaled
+    float4 phr[PD_MTP];
+    {
+        const int lane = tid & 63, q = lane >> 4, col = lane & 15, tt = wave & 3, part = wave >> 2;
+        const int tl = 16 * tt + col;
+        const int mt0 = part * PD_MTP, mt1 = min(MT, mt0 + PD_MTP);
+        const float *PHrow = f.PH + ((int64_t)b * T + t0 + tl) * A;
+#pragma unroll
+        for (int j = 0; j < PD_MTP; ++j) {
+            const float4 v = e2_load_ph(PHrow, tl < nrows && mt0 + j < mt1, 16 * (mt0 + j) + 4 * q, A, f.PH);
+            phr[j] = make_float4(v.x * K2L, v.y * K2L, v.z * K2L, v.w * K2L);
+        }
+    }
+    // ---- dalpha role: hbatch tile, lane (frame tid >> 3, column group tid & 7)
+    float4 hreg[PD_HF];
+    {
+        const int tf = tid >> 3, cgp = tid & 7;
+        const float *hb = f.hbatch + ((int64_t)b * T + t0 + tf) * E + cgp * ECG;
+#pragma unroll
+        for (int i = 0; i < PD_HF; ++i) {
+            const bool ok = tf < nrows && 4 * i < ECG && cgp * ECG + 4 * i < E;
+            const float4 v = ld4(ok ? hb + 4 * i : f.hbatch);
+            const unsigned mk = ok ? 0xffffffffu : 0u;
+            hreg[i] = make_float4(__uint_as_float(__float_as_uint(v.x) & mk), __uint_as_float(__float_as_uint(v.y) & mk),
+                                  __uint_as_float(__float_as_uint(v.z) & mk), __uint_as_float(__float_as_uint(v.w) & mk));
+        }
+    }
+    // ---- job roles
+    const int NX = p.NJX * MTB, NG = p.NJG * 2 * MTB;
+    const bool is_x = w < NX, is_g = !is_x && w < NX + NG;
+    const int jq = is_x ? w : w - NX;
+    const int gh = is_g ? (jq & 1) : 0;                    // G: half of the reduction
+    const int jr = is_g ? (jq >> 1) : jq;
+    const int jt = jr / MTB, jb0 = 16 * (jr - jt * MTB);   // 16-wide tile along units (X) / columns of E (G), first row
+    const int KH = 2 * Hd;                                  // reduction length of every pass (= A = half of 4 Hd)
+    int kqK = (KH + 31) / 32;
+    kqK = (kqK + 3) & ~3;
+    const int NGR_A = A / 4, NGR_R = Hd;                    // granules per row: dsp (A / 4), drec (4 Hd / 4)
+    float dC_reg = 0.f, accW_reg = 0.f;                     // X owner threads (tid < 256): row tid >> 4, unit tid & 15
+    __syncthreads();
+
+    for (int n = 0; n < L; ++n) {
+        const int s = L - 1 - n;
+        const int slot = n & 1, pslot = slot ^ 1;
+        const unsigned ep = (unsigned)((n >> 1) & 1), pep = (unsigned)(((n - 1) >> 1) & 1);
+        PD_STAMP(0);
+        // ---- X. cell backward of step s for 16 rows x 16 units
+        if (is_x) {
+            const int tid = pd_opaque((int)threadIdx.x);
+            const int lane = tid & 63, wave = tid >> 6, q = lane >> 4, ji = lane & 15;
+            const int jrow = jb0 + ji, ju = 16 * jt + ji;
+            const int kb = (wave * 4 + q) * kqK, ke = min(KH, kb + kqK);
+            const int obi = tid >> 4, oej = tid & 15;
+            const int ob = jb0 + obi, oj = 16 * jt + oej;
+            const bool owner = tid < 256 && ob < B && oj < Hd;
+            float ig = 0.f, fg = 0.f, gg = 0.f, og = 0.f, cn = 0.f, cp = 0.f;
+            if (owner) {
+                const float *gd = f.gates + (int64_t)s * 4 * BH + (int64_t)ob * 4 * Hd;
+                ig = gd[oj]; fg = gd[Hd + oj]; gg = gd[2 * Hd + oj]; og = gd[3 * Hd + oj];
+                cn = f.C[(int64_t)(s + 1) * BH + (int64_t)ob * Hd + oj];
+                cp = f.C[(int64_t)s * BH + (int64_t)ob * Hd + oj];
+            }
+            float dS = 0.f;
+            if (n > 0) {
+                const float *wrow = ju < Hd ? a.W_seT + (int64_t)ju * A : nullptr;
+                float4 wv[PD_KF];
+#pragma unroll
+                for (int fq = 0; fq < PD_KF; ++fq) wv[fq] = t16_load_fast(wrow, kb + 4 * fq, ke, a.W_seT);
+                int off[PD_KF];
+#pragma unroll
+                for (int fq = 0; fq < PD_KF; ++fq)
+                    off[fq] = (jrow < B && kb + 4 * fq < ke)
+                                  ? (pslot * NGR_A * 4 * B + ((kb >> 2) + fq) * 4 * B + 4 * jrow) * 4 : PD_OOB;
+                float4 av[PD_KF];
+                pd_gather<PD_KF>(av, rX, off, pep, off[0], s_abort, p.err);
+                PD_STAMP(1);
+                Tile16Acc acc;
+                tile16_init(acc);
+#pragma unroll
+                for (int fq = 0; fq < PD_KF; ++fq) {
+                    acc.a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[fq].x, wv[fq].x, acc.a0, 0, 0, 0);
+                    acc.a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[fq].y, wv[fq].y, acc.a1, 0, 0, 0);
+                    acc.a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[fq].z, wv[fq].z, acc.a0, 0, 0, 0);
+                    acc.a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[fq].w, wv[fq].w, acc.a1, 0, 0, 0);
+                }
+                tile16_reduce(acc, red16);
+                if (*s_abort) return;
+                if (tid < 256) dS = tile16_get(red16, obi, oej) + accW_reg;
+            }
+            if (tid < 256) {
+                float dr[4] = {0.f, 0.f, 0.f, 0.f};
+                if (owner) {
+                    const float tc = tanh_f(cn);
+                    const float dO = dS * tc;
+                    const float dc = dS * og * (1.f - tc * tc) + dC_reg;
+                    dr[0] = dc * gg * ig * (1.f - ig);
+                    dr[1] = dc * cp * fg * (1.f - fg);
+                    dr[2] = dc * ig * (1.f - gg * gg);
+                    dr[3] = dO * og * (1.f - og);
+                    dC_reg = dc * fg;
+                    float *dp = a.drec + (int64_t)s * 4 * BH + (int64_t)ob * 4 * Hd;
+                    dp[oj] = dr[0]; dp[Hd + oj] = dr[1]; dp[2 * Hd + oj] = dr[2]; dp[3 * Hd + oj] = dr[3];
+                }
+                // 4 units of a row sit on 4 adjacent lanes: one tagged 16-byte granule per (row, gate, unit quad)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const float v0 = dr[g];
+                    const float v1 = ASR_DPP(v0, 0x55), v2 = ASR_DPP(v0, 0xAA), v3 = ASR_DPP(v0, 0xFF);
+                    if ((oej & 3) == 0 && ob < B && oj < Hd)
+                        pd_st4_tag(rX, (p.o_drec + slot * NGR_R * 4 * B + ((g * Hd + oj) >> 2) * 4 * B + 4 * ob) * 4,
+                                   make_float4(v0, v1, v2, v3), ep);
+                }
+            }
+            PD_STAMP(2);
+            // ---- X2 (off the chain). drec_s W_ss + dyp_s W_sy for the next step's dS, kept in a register
+            if (n + 1 < L) {
+                Tile16Acc acc;
+                tile16_init(acc);
+                const float *wrow = ju < Hd ? a.W_ssT + (int64_t)ju * 4 * Hd : nullptr;
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {
+                    float4 wv[PD_KF];
+#pragma unroll
+                    for (int fq = 0; fq < PD_KF; ++fq)
+                        wv[fq] = t16_load_fast(wrow ? wrow + c * KH : nullptr, kb + 4 * fq, ke, a.W_ssT);
+                    int off[PD_KF];
+#pragma unroll
+                    for (int fq = 0; fq < PD_KF; ++fq)
+                        off[fq] = (jrow < B && kb + 4 * fq < ke)
+                                      ? (p.o_drec + slot * NGR_R * 4 * B + (((c * KH + kb) >> 2) + fq) * 4 * B + 4 * jrow) * 4
+                                      : PD_OOB;
+                    float4 av[PD_KF];
+                    pd_gather<PD_KF>(av, rX, off, ep, off[0], s_abort, p.err);
+#pragma unroll
+                    for (int fq = 0; fq < PD_KF; ++fq) {
+                        acc.a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[fq].x, wv[fq].x, acc.a0, 0, 0, 0);
+                        acc.a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[fq].y, wv[fq].y, acc.a1, 0, 0, 0);
+                        acc.a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[fq].z, wv[fq].z, acc.a0, 0, 0, 0);
+                        acc.a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[fq].w, wv[fq].w, acc.a1, 0, 0, 0);
+                    }
+                }
+                tile16_reduce(acc, red16b);
+                if (*s_abort) return;
+                if (tid < 256)
+                    accW_reg = tile16_get(red16b, obi, oej) + (owner ? p.Q1[(int64_t)s * BH + (int64_t)ob * Hd + oj] : 0.f);
+            }
+        }
+        // ---- G. one half of dg_s = drec_s W_gs + dyp_s W_gy for 16 rows x 16 columns
+        if (is_g) {
+            const int tid = pd_opaque((int)threadIdx.x);
+            const int lane = tid & 63, wave = tid >> 6, q = lane >> 4, ji = lane & 15;
+            const int jrow = jb0 + ji, je = 16 * jt + ji;
+            const int kb = (wave * 4 + q) * kqK, ke = min(KH, kb + kqK);
+            const float *wrow = je < E ? a.W_gsT + (int64_t)je * 4 * Hd + gh * KH : nullptr;
+            float4 wv[PD_KF];
+#pragma unroll
+            for (int fq = 0; fq < PD_KF; ++fq) wv[fq] = t16_load_fast(wrow, kb + 4 * fq, ke, a.W_gsT);
+            int off[PD_KF];
+#pragma unroll
+            for (int fq = 0; fq < PD_KF; ++fq)
+                off[fq] = (jrow < B && kb + 4 * fq < ke)
+                              ? (p.o_drec + slot * NGR_R * 4 * B + (((gh * KH + kb) >> 2) + fq) * 4 * B + 4 * jrow) * 4 : PD_OOB;
+            float4 av[PD_KF];
+            pd_gather<PD_KF>(av, rX, off, ep, off[0], s_abort, p.err);
+            PD_STAMP(3);
+            Tile16Acc acc;
+            tile16_init(acc);
+#pragma unroll
+            for (int fq = 0; fq < PD_KF; ++fq) {
+                acc.a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[fq].x, wv[fq].x, acc.a0, 0, 0, 0);
+                acc.a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[fq].y, wv[fq].y, acc.a1, 0, 0, 0);
+                acc.a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[fq].z, wv[fq].z, acc.a0, 0, 0, 0);
+                acc.a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[fq].w, wv[fq].w, acc.a1, 0, 0, 0);
+            }
+            tile16_reduce(acc, red16);
+            if (*s_abort) return;
+            if (tid < 64) {
+                const int bi = tid >> 2, n4 = (tid & 3) * 4;
+                const int bb = jb0 + bi, e0 = 16 * jt + n4;
+                if (bb < B && e0 < E) {
+                    float4 v = make_float4(tile16_get(red16, bi, n4), tile16_get(red16, bi, n4 + 1),
+                                           tile16_get(red16, bi, n4 + 2), tile16_get(red16, bi, n4 + 3));
+                    if (gh == 0) {
+                        const float4 q2 = ld4(p.Q2 + (int64_t)s * BE + (int64_t)bb * E + e0);
+                        v.x += q2.x; v.y += q2.y; v.z += q2.z; v.w += q2.w;
+                    }
+                    pd_st4_tag(rX, (p.o_dgp + ((slot * 2 + gh) * B + bb) * E + e0) * 4, v, ep);
+                }
+            }
+            PD_STAMP(4);
+        }
+        if (nrows > 0) {
+            // ---- CV (off the chain). conv^T of the neighbours' dF_{s+1}; this step's alpha / conv features / sproj
+            {
+                const int tid = pd_opaque((int)threadIdx.x);
+                for (int i = tid; i < TT; i += PD_THREADS)
+                    altile[i] = i < nrows ? f.alpha[(int64_t)s * BT + (int64_t)b * T + t0 + i] : 0.f;
+                for (int i = tid; i < TT * 12; i += PD_THREADS) {
+                    const int r = i / 12, c = i - 12 * r;
+                    m.Fs[i] = (r < nrows && c < NCH) ? f.Fc[(((int64_t)s * B + b) * T + t0 + r) * NCH + c] : 0.f;
+                }
+                if (4 * tid < A) {
+                    const float4 v = ld4(f.sproj + (int64_t)s * BA + (int64_t)b * A + 4 * tid);
+                    *reinterpret_cast<float4 *>(m.sp + 4 * tid) = make_float4(v.x * K2L, v.y * K2L, v.z * K2L, v.w * K2L);
+                }
+                if (n > 0) {
+                    if ((tid >> 6) * 64 < 163 * 3) {      // wave-uniform
+                        const int r = tid / 3, gq = tid - 3 * r;
+                        const int t = t0 - (KW - 1 - PADW) + r;
+                        const bool ok = tid < 163 * 3 && t >= 0 && t < len;
+                        const int off[1] = {ok ? (p.o_dF + ((pslot * B + b) * Tp + t) * 12 + 4 * gq) * 4 : PD_OOB};
+                        float4 v[1];
+                        pd_gather<1>(v, rX, off, pep, PD_OOB, s_abort, p.err);
+                        if (tid < 163 * 3) *reinterpret_cast<float4 *>(xw + 4 * tid) = v[0];
+                    }
+                }
+            }
+            __syncthreads();
+            if (*s_abort) return;
+            if (n > 0) {
+                const int tid = pd_opaque((int)threadIdx.x);
+                const int lane = tid & 63, wave = tid >> 6, q = lane >> 4, col = lane & 15;
+                f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+                const float *xa = xw + 192 * (col & 3) + q;
+                const float *kb_ = kfp + 180 - 12 * col + q;
+                const int ks0 = wave * 44;
+#pragma unroll 4
+                for (int u = 0; u < 44; u += 2) {
+                    const int ka = ks0 + u, kc = ks0 + u + 1;
+                    const float a0 = ka < PB_NKS ? xa[4 * ka] : 0.f, b0 = ka < PB_NKS ? kb_[4 * ka] : 0.f;
+                    const float a1 = kc < PB_NKS ? xa[4 * kc] : 0.f, b1 = kc < PB_NKS ? kb_[4 * kc] : 0.f;
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b0, acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b1, acc1, 0, 0, 0);
+                }
+                if (lane < 16) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) dcvw[wave * TT + 16 * r + lane] = acc0[r] + acc1[r];
+                }
+                __syncthreads();
+                if (tid < TT) {
+                    float v = 0.f;
+#pragma unroll
+                    for (int wv = 0; wv < PD_WAVES; ++wv) v += dcvw[wv * TT + tid];
+                    dcv[tid] = v;
+                }
+            }
+            PD_STAMP(5);
+            // ---- DA. dg_s[b] (two partials), dalpha tile, <alpha, dalpha>, de
+            {
+                const int tid = pd_opaque((int)threadIdx.x);
+                const int lane = tid & 63, wave = tid >> 6;
+                if (wave * 256 < E) {      // wave-uniform
+                    const bool act = 4 * tid < E;
+                    const int off[2] = {act ? (p.o_dgp + ((slot * 2 + 0) * B + b) * E + 4 * tid) * 4 : PD_OOB,
+                                        act ? (p.o_dgp + ((slot * 2 + 1) * B + b) * E + 4 * tid) * 4 : PD_OOB};
+                    float4 v[2];
+                    pd_gather<2>(v, rX, off, ep, PD_OOB, s_abort, p.err);
+                    if (act) {
+                        const float4 d4 = make_float4(v[0].x + v[1].x, v[0].y + v[1].y, v[0].z + v[1].z, v[0].w + v[1].w);
+                        *reinterpret_cast<float4 *>(dgs + 4 * tid) = d4;
+                        if (k == 0) *reinterpret_cast<float4 *>(a.dg + (int64_t)s * BE + (int64_t)b * E + 4 * tid) = d4;
+                    }
+                }
+                __syncthreads();
+                if (*s_abort) return;
+                PD_STAMP(6);
+                const int tf = tid >> 3, cgp = tid & 7;
+                float acc = 0.f;
+                const float *dgp = dgs + cgp * ECG;
+#pragma unroll
+                for (int i = 0; i < PD_HF; ++i) {
+                    const float4 d4 = *reinterpret_cast<const float4 *>(dgp + 4 * i);
+                    acc += hreg[i].x * d4.x + hreg[i].y * d4.y + hreg[i].z * d4.z + hreg[i].w * d4.w;
+                }
+                acc += ASR_DPP(acc, 0xB1);     // quad_perm [1,0,3,2]
+                acc += ASR_DPP(acc, 0x4E);     // quad_perm [2,3,0,1]
+                acc += ASR_DPP(acc, 0x141);    // row_half_mirror: the other quad of the 8 lanes
+                const float da = acc + dcv[tf];
+                const float al_ = altile[tf];
+                if (cgp == 0) pdot[tf] = tf < nrows ? al_ * da : 0.f;
+                __syncthreads();
+                if (wave == 0) {
+                    const float v = wave_sum(pdot[lane]);
+                    if (lane == 0) pd_st4_tag(rX, (p.o_dot + ((slot * B + b) * NTILE + k) * 4) * 4, make_float4(v, 0.f, 0.f, 0.f), ep);
+                    const int off[1] = {lane < nact ? (p.o_dot + ((slot * B + b) * NTILE + lane) * 4) * 4 : PD_OOB};
+                    float4 dv[1];
+                    pd_gather<1>(dv, rX, off, ep, PD_OOB, s_abort, p.err);
+                    const float d = wave_sum(lane < nact ? dv[0].x : 0.f);
+                    if (lane == 0) *sdot = d;
+                }
+                __syncthreads();
+                if (*s_abort) return;
+                const float de = al_ * (da - *sdot);
+                if (cgp == 0) {
+                    detile[tf] = tf < nrows ? de : 0.f;
+                    if (tf < nrows) a.de[(int64_t)s * BT + (int64_t)b * T + t0 + tf] = de;
+                }
+                __syncthreads();
+            }
+            PD_STAMP(7);
+            // ---- EB. dpre = de w sech^2(pre): dsp partial over this tile's frames, dF tile
+            {
+                const int tid = pd_opaque((int)threadIdx.x);
+                const int lane = tid & 63, wave = tid >> 6, q = lane >> 4, col = lane & 15, tt = wave & 3, part = wave >> 2;
+                const int tl = 16 * tt + col;
+                const int mt0 = part * PD_MTP;
+                const float de4 = 4.0f * detile[tl];
+                float fB[3];
+#pragma unroll
+                for (int ks = 0; ks < 3; ++ks) fB[ks] = m.Fs[tl * 12 + 4 * ks + q];
+                struct PBTile { float4 s4, w4; float a0, a1, a2; };
+                auto ldt = [&](int mt) {
+                    PBTile t;
+                    t.s4 = *reinterpret_cast<const float4 *>(m.sp + 16 * mt + 4 * q);
+                    const float *wr = m.wfe + (16 * mt + col) * 12 + q;
+                    t.a0 = wr[0]; t.a1 = wr[4]; t.a2 = wr[8];
+                    t.w4 = *reinterpret_cast<const float4 *>(m.wee + 16 * mt + 4 * q);
+                    return t;
+                };
+                f32x4 dF0 = {0.f, 0.f, 0.f, 0.f}, dF1 = {0.f, 0.f, 0.f, 0.f};   // K2L * dF^T[c = 4q + r][t = col], partial over a
+                PBTile c0 = ldt(mt0), c1 = ldt(mt0 + 1);
+#pragma unroll
+                for (int j = 0; j < PD_MTP; j += 2) {
+                    PBTile n0 = c0, n1 = c1;
+                    if (j + 2 < PD_MTP) { n0 = ldt(mt0 + j + 2); n1 = ldt(mt0 + j + 3); }
+                    f32x4 x0 = {phr[j].x + c0.s4.x, phr[j].y + c0.s4.y, phr[j].z + c0.s4.z, phr[j].w + c0.s4.w};
+                    f32x4 x1 = {phr[j + 1].x + c1.s4.x, phr[j + 1].y + c1.s4.y, phr[j + 1].z + c1.s4.z, phr[j + 1].w + c1.s4.w};
+                    x0 = __builtin_amdgcn_mfma_f32_16x16x4f32(c0.a0, fB[0], x0, 0, 0, 0);
+                    x1 = __builtin_amdgcn_mfma_f32_16x16x4f32(c1.a0, fB[0], x1, 0, 0, 0);
+                    x0 = __builtin_amdgcn_mfma_f32_16x16x4f32(c0.a1, fB[1], x0, 0, 0, 0);
+                    x1 = __builtin_amdgcn_mfma_f32_16x16x4f32(c1.a1, fB[1], x1, 0, 0, 0);
+                    x0 = __builtin_amdgcn_mfma_f32_16x16x4f32(c0.a2, fB[2], x0, 0, 0, 0);
+                    x1 = __builtin_amdgcn_mfma_f32_16x16x4f32(c1.a2, fB[2], x1, 0, 0, 0);
+                    // sech^2 = 4 E / (1 + E)^2, E = 2^(-|x|) (x carries the factor 2 log2 e); the 4 rides in de4
+                    float dp0[4], dp1[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float e0 = __builtin_amdgcn_exp2f(-fabsf(x0[r])), e1 = __builtin_amdgcn_exp2f(-fabsf(x1[r]));
+                        const float r0 = __builtin_amdgcn_rcpf(1.0f + e0), r1 = __builtin_amdgcn_rcpf(1.0f + e1);
+                        dp0[r] = e0 * r0 * r0;
+                        dp1[r] = e1 * r1 * r1;
+                    }
+                    dp0[0] *= de4 * c0.w4.x; dp0[1] *= de4 * c0.w4.y; dp0[2] *= de4 * c0.w4.z; dp0[3] *= de4 * c0.w4.w;
+                    dp1[0] *= de4 * c1.w4.x; dp1[1] *= de4 * c1.w4.y; dp1[2] *= de4 * c1.w4.z; dp1[3] *= de4 * c1.w4.w;
+                    // dF^T[c][t] += sum_a W_fe[a][c] dpre[t][a]: k-step r pairs a = 16 mt + 4 q + r on both operands
+                    const float *wc0 = m.wfe + (16 * (mt0 + j) + 4 * q) * 12 + col;
+                    const float *wc1 = wc0 + 16 * 12;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        dF0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wc0[r * 12], dp0[r], dF0, 0, 0, 0);
+                        dF1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wc1[r * 12], dp1[r], dF1, 0, 0, 0);
+                    }
+                    const float t0_ = row16_sum4(dp0[0], dp0[1], dp0[2], dp0[3]);
+                    const float t1_ = row16_sum4(dp1[0], dp1[1], dp1[2], dp1[3]);
+                    if ((col & 3) == 0) {
+                        m.dspl[tt * PD_AL + 16 * (mt0 + j) + 4 * q + (col >> 2)] = t0_;
+                        m.dspl[tt * PD_AL + 16 * (mt0 + j + 1) + 4 * q + (col >> 2)] = t1_;
+                    }
+                    c0 = n0; c1 = n1;
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) m.dFl[(part * TT + tl) * 16 + 4 * q + r] = dF0[r] + dF1[r];
+                __syncthreads();
+                // dsp partial of this tile (sum over its 4 x 16 frames), 16-byte tagged granules
+                if (4 * tid < A) {
+                    const float4 u0 = *reinterpret_cast<const float4 *>(m.dspl + 4 * tid);
+                    const float4 u1 = *reinterpret_cast<const float4 *>(m.dspl + PD_AL + 4 * tid);
+                    const float4 u2 = *reinterpret_cast<const float4 *>(m.dspl + 2 * PD_AL + 4 * tid);
+                    const float4 u3 = *reinterpret_cast<const float4 *>(m.dspl + 3 * PD_AL + 4 * tid);
+                    pd_st4_tag(rX, (p.o_dspp + ((slot * B + b) * NTILE + k) * A16 + 4 * tid) * 4,
+                               make_float4((u0.x + u1.x) + (u2.x + u3.x), (u0.y + u1.y) + (u2.y + u3.y),
+                                           (u0.z + u1.z) + (u2.z + u3.z), (u0.w + u1.w) + (u2.w + u3.w)), ep);
+                }
+                // dF tile: published for the neighbours' conv^T of the next step (12 floats a frame) and saved
+                if (tid < 3 * TT) {
+                    const int r = tid / 3, gq = tid - 3 * r;
+                    if (r < nrows) {
+                        constexpr float IK = 1.0f / K2L;
+                        float v[4];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const int c = 4 * gq + e;
+                            v[e] = c < NCH ? (m.dFl[r * 16 + c] + m.dFl[(TT + r) * 16 + c]) * IK : 0.f;
+                        }
+                        pd_st4_tag(rX, (p.o_dF + ((slot * B + b) * Tp + t0 + r) * 12 + 4 * gq) * 4,
+                                   make_float4(v[0], v[1], v[2], v[3]), ep);
+                        float *dFo = a.dF + (((int64_t)s * B + b) * T + t0 + r) * NCH + 4 * gq;
+                        dFo[0] = v[0]; dFo[1] = v[1];
+                        if (gq < 2) { dFo[2] = v[2]; dFo[3] = v[3]; }
+                    }
+                }
+            }
+            PD_STAMP(8);
+        }
+        // ---- RD. dsp_s[b, chunk k] = sum of the tiles' partials  (dsp_0 multiplies S_0 = 0: not needed)
+        if (s > 0) {
+            const int tid = pd_opaque((int)threadIdx.x);
+            const int ncg = ECH / 4;
+            const int kk = tid / ncg, g4 = tid - kk * ncg;
+            const int colA = k * ECH + 4 * g4;
+            if ((tid >> 6) * 64 < nact * ncg) {     // wave-uniform
+                const bool act = kk < nact && colA < A;
+                const int off[1] = {act ? (p.o_dspp + ((slot * B + b) * NTILE + kk) * A16 + colA) * 4 : PD_OOB};
+                float4 v[1];
+                pd_gather<1>(v, rX, off, ep, PD_OOB, s_abort, p.err);
+                if (kk < nact) *reinterpret_cast<float4 *>(rbuf + kk * ECH + 4 * g4) = act ? v[0] : zero4();
+            }
+            __syncthreads();
+            if (*s_abort) return;
+            if (tid < ncg && k * ECH + 4 * tid < A) {
+                float4 d4 = zero4();
+                for (int t = 0; t < nact; ++t) {
+                    const float4 v = *reinterpret_cast<const float4 *>(rbuf + t * ECH + 4 * tid);
+                    d4.x += v.x; d4.y += v.y; d4.z += v.z; d4.w += v.w;
+                }
+                const int ca = k * ECH + 4 * tid;
+                pd_st4_tag(rX, (slot * NGR_A * 4 * B + (ca >> 2) * 4 * B + 4 * b) * 4, d4, ep);
+                *reinterpret_cast<float4 *>(a.dsp + (int64_t)s * BA + (int64_t)b * A + ca) = d4;
+            }
+        }
+        PD_STAMP(9);
+    }
+}
+
 static int64_t bwd_ntile(int T) { return cdiv(T, TT); }
 
-extern "C" int64_t asr_attdec_bwd_ws_floats(int B, int T, int E, int Hd, int L) {
+static int64_t attdec_bwd_ws_base_floats(int B, int T, int E, int Hd, int L) {
     (void)E;
     const int64_t A = 2 * Hd, nt = bwd_ntile(T);
     int64_t n = 0;
@@ -2181,7 +2697,22 @@ extern "C" int64_t asr_attdec_bwd_ws_floats(int B, int T, int E, int Hd, int L) 
     int64_t conv = (int64_t)(L > 1 ? L - 1 : 1) * B * NCH * KW + 64 +
                    asr_colsum_ws_floats((L > 1 ? L - 1 : 1) * B, NCH * KW) + 64;
     n += post > conv ? post : conv;
-    return n;
+    return (n + 63) & ~(int64_t)63;
+}
+// persistent loop kernel: Q1 (L,B,Hd) | Q2 (L,B,E) | exchange area | 64 | error word | 63
+static int64_t attdec_bwd_xch_floats(int B, int T, int E, int Hd) {
+    const int64_t A = 2 * Hd, A16 = (A + 15) & ~15, nt = bwd_ntile(T);
+    return 2 * ((int64_t)A * B + 4 * (int64_t)Hd * B + 2 * (int64_t)B * E + (int64_t)B * nt * 4 + (int64_t)B * nt * A16 +
+                (int64_t)B * nt * TT * 12);
+}
+extern "C" int64_t asr_attdec_bwd_ws_floats(int B, int T, int E, int Hd, int L) {
+    return attdec_bwd_ws_base_floats(B, T, E, Hd, L) + (((int64_t)L * B * (Hd + E) + 63) & ~(int64_t)63) +
+           attdec_bwd_xch_floats(B, T, E, Hd) + 64 + 64;
+}
+// Index (in floats) inside asr_attdec_bwd's workspace of the persistent backward kernel's sticky error word
+// (non-zero after the call iff an in-launch wait timed out: the gradients are then invalid).
+extern "C" int64_t asr_attdec_bwd_err_offset(int B, int T, int E, int Hd, int L) {
+    return asr_attdec_bwd_ws_floats(B, T, E, Hd, L) - 64;
 }
 
 extern "C" int asr_attdec_bwd(const asr_attdec_bwd_args *a, void *stream) {
@@ -2241,7 +2772,69 @@ extern "C" int asr_attdec_bwd(const asr_attdec_bwd_args *a, void *stream) {
     // dscell sums the per-tile dsp partials into LDS (16 rows x A) when that fits beside its tile buffer
     const size_t ds_smem = sizeof(float) * 16 * (size_t)A;
     const int ds_lds = (vecT && A % 4 == 0 && ds_smem <= 44 * 1024) ? 1 : 0;
-    for (int s = L - 1; s >= 0; --s) {
+    bool persistent = false;
+    ASR_CHECK_HIP(hipMemsetAsync(a->ws + asr_attdec_bwd_err_offset(B, T, E, Hd, L), 0, sizeof(unsigned), st));
+    {   // one launch for the whole loop when every workgroup of the (B x frame tile) grid gets a compute unit of its own
+        static int n_cu = -1;
+        if (n_cu < 0) {
+            int dev = 0;
+            if (hipGetDevice(&dev) != hipSuccess ||
+                hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
+                n_cu = 0;
+        }
+        PBParams p;
+        p.NTILE = (int)nt;
+        p.MTB = cdiv(B, 16);
+        p.NJX = cdiv(Hd, 16);
+        p.NJG = cdiv(E, 16);
+        p.ECG = ((cdiv(E, 8) + 3) / 4) * 4;
+        p.ECH = ((cdiv(A, (int)nt) + 3) / 4) * 4;
+        p.A16 = A16p;
+        p.Tp = (int)nt * TT;
+        const int64_t nwg = (int64_t)B * nt;
+        const int64_t xfl = attdec_bwd_xch_floats(B, T, E, Hd);
+        const size_t psm = attdec_bwd_persist_smem();
+        if (attdec_persist_on() && use_v2 && vecH && vecT && A % 16 == 0 && E % 4 == 0 && nwg <= n_cu &&
+            (int64_t)(p.NJX + 2 * p.NJG) * p.MTB <= nwg && A16p <= PD_AL && p.ECG <= 4 * PD_HF && 2 * Hd <= 128 * PD_KF &&
+            p.ECH * 8 <= PD_AL && nt <= 8 && nt <= 64 && xfl * 4 < (int64_t)0x7fff0000 && psm <= 150 * 1024 &&
+            al16(a->dg) && al16(a->dsp) && al16(a->ws) && al16(f->sproj)) {
+            static thread_local bool attr3 = false;
+            if (!attr3) {
+                ASR_CHECK_HIP(hipFuncSetAttribute((const void *)attdec_bwd_persist_kernel,
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+                attr3 = true;
+            }
+            float *q1 = a->ws + attdec_bwd_ws_base_floats(B, T, E, Hd, L);
+            float *q2 = q1 + (int64_t)L * B * Hd;
+            // hoisted: Q1 = dyp W_sy, Q2 = dyp W_gy for all steps (the per-step kernels redo them row tile by row tile)
+            asr_gemm_desc d;
+            memset(&d, 0, sizeof(d));
+            d.A = a->dyp; d.M = L * B; d.K = Hd; d.a_s0 = Hd;
+            d.alpha = 1.0f; d.splitk = 1; d.nbatch = 1;
+            d.B = a->W_syT; d.N = Hd; d.b_s0 = Hd; d.C = q1; d.c_s0 = Hd;
+            ASR_CHECK(asr_sgemm(&d, stream));
+            d.B = a->W_gyT; d.N = E; d.b_s0 = Hd; d.C = q2; d.c_s0 = E;
+            ASR_CHECK(asr_sgemm(&d, stream));
+            p.a = *a;
+            p.tab = tab;
+            p.Q1 = q1;
+            p.Q2 = q2;
+            p.xch = q1 + (((int64_t)L * B * (Hd + E) + 63) & ~(int64_t)63);
+            p.o_drec = 2 * A * B;
+            p.o_dgp = p.o_drec + 8 * Hd * B;
+            p.o_dot = p.o_dgp + 4 * B * E;
+            p.o_dspp = p.o_dot + 8 * B * (int)nt;
+            p.o_dF = p.o_dspp + 2 * B * (int)nt * A16p;
+            p.xch_bytes = (int)(xfl * 4);
+            p.err = reinterpret_cast<unsigned *>(a->ws + asr_attdec_bwd_err_offset(B, T, E, Hd, L));
+            p.stamps = g_attdec_stamps;
+            ASR_CHECK_HIP(hipMemsetAsync(p.xch, 0xFF, sizeof(float) * (size_t)xfl, st));
+            hipLaunchKernelGGL(attdec_bwd_persist_kernel, dim3((unsigned)nwg), dim3(PD_THREADS), psm, st, p);
+            ASR_CHECK_LAUNCH("attdec_bwd_persist_kernel");
+            persistent = true;
+        }
+    }
+    for (int s = persistent ? -1 : L - 1; s >= 0; --s) {
         const bool has_next = s + 1 < L;
         hipLaunchKernelGGL(dscell_kernel, dim3(cdiv(Hd, 16), cdiv(B, 16)), dim3(1024), ds_lds ? ds_smem : 0, st, s, L,
                            has_next ? a->drec + (s + 1) * 4 * BH : (const float *)nullptr,

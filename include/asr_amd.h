@@ -498,6 +498,11 @@ typedef struct {
 
 int64_t asr_attdec_bwd_ws_floats(int B, int T, int E, int Hd, int L);
 int asr_attdec_bwd(const asr_attdec_bwd_args *a, void *stream);
+/* Like asr_attdec_fwd, asr_attdec_bwd runs its L-step loop as ONE persistent launch when the shape fits (same
+ * switch: asr_attdec_persist / ASR_ATTDEC_PERSIST), else four launches per label step.
+ * asr_attdec_bwd_err_offset: index (in floats) inside a->ws of a 4-byte word that is non-zero after the call iff an
+ * in-launch wait timed out (gradients invalid) -- fold it into a gradient with asr_poison_if_flag. */
+int64_t asr_attdec_bwd_err_offset(int B, int T, int E, int Hd, int L);
 
 #ifdef __cplusplus
 }
