@@ -2242,6 +2242,25 @@ __global__ __launch_bounds__(PD_THREADS) void attdec_bwd_persist_kernel(PBParams
     const int64_t BH = (int64_t)B * Hd, BT = (int64_t)B * T, BA = (int64_t)B * A, BE = (int64_t)B * E;
     __amdgpu_buffer_rsrc_t rX = __builtin_amdgcn_make_buffer_rsrc(p.xch, 0, p.xch_bytes, 0x00020000);
 
+    int *rank_s = reinterpret_cast<int *>(sred + 36);
+    {   // rank of this workgroup among all of them by (frames in the tile, index)
+        int *keys = reinterpret_cast<int *>(xw);
+        const int nwg = gridDim.x;      // <= 256 compute units <= PD_THREADS
+        if (tid < nwg) {
+            const int bb = tid / NTILE, kk = tid - bb * NTILE;
+            keys[tid] = max(0, min(TT, min(f.lengths[bb], T) - kk * TT)) * 4096 + tid;
+        }
+        __syncthreads();
+        const float c = wave_sum((tid < nwg && keys[tid] < keys[w]) ? 1.0f : 0.0f);
+        if ((tid & 63) == 0) sred[wave] = c;
+        __syncthreads();
+        if (tid == 0) {
+            float r = 0.f;
+            for (int i = 0; i < PD_WAVES; ++i) r += sred[i];
+            *rank_s = (int)r;
+        }
+        __syncthreads();
+    }
     for (int i = tid; i < PD_AL * 12; i += PD_THREADS) m.wfe[i] = i < A16 * 12 ? p.tab[i] * K2L : 0.f;
     for (int i = tid; i < PD_AL; i += PD_THREADS) {
         m.wee[i] = i < A16 ? p.tab[A16 * 12 + i] : 0.f;
@@ -2286,10 +2305,13 @@ __global__ __launch_bounds__(PD_THREADS) void attdec_bwd_persist_kernel(PBParams
                                   __uint_as_float(__float_as_uint(v.z) & mk), __uint_as_float(__float_as_uint(v.w) & mk));
         }
     }
-    // ---- job roles
+    // ---- job roles, dealt by load: the workgroups are ranked by the frames their tile holds (ties by index), the X
+    // jobs go to the lightest ones (a tile past its utterance's end has no attention work at all), the G jobs to the
+    // next, the fullest tiles stay job-free.  Every workgroup computes the same ranking from the lengths.
     const int NX = p.NJX * MTB, NG = p.NJG * 2 * MTB;
-    const bool is_x = w < NX, is_g = !is_x && w < NX + NG;
-    const int jq = is_x ? w : w - NX;
+    const int jrank = *rank_s;
+    const bool is_x = jrank < NX, is_g = !is_x && jrank < NX + NG;
+    const int jq = is_x ? jrank : jrank - NX;
     const int gh = is_g ? (jq & 1) : 0;                    // G: half of the reduction
     const int jr = is_g ? (jq >> 1) : jq;
     const int jt = jr / MTB, jb0 = 16 * (jr - jt * MTB);   // 16-wide tile along units (X) / columns of E (G), first row
@@ -2300,6 +2322,48 @@ __global__ __launch_bounds__(PD_THREADS) void attdec_bwd_persist_kernel(PBParams
     float dC_reg = 0.f, accW_reg = 0.f;                     // X owner threads (tid < 256): row tid >> 4, unit tid & 15
     __syncthreads();
 
+    // ---- X2 (off the chain). drec_s W_ss + dyp_s W_sy for the next step's dS, kept in a register.  A workgroup
+    // whose tile holds no frames runs it right behind its X job, one with attention work at the end of the step:
+    // either way it is done long before the next dsp arrives.
+    auto do_x2 = [&](int n, int s, int slot, unsigned ep) {
+        (void)n;
+            const int tid = pd_opaque((int)threadIdx.x);
+            const int lane = tid & 63, wave = tid >> 6, q = lane >> 4, ji = lane & 15;
+            const int jrow = jb0 + ji, ju = 16 * jt + ji;
+            const int kb = (wave * 4 + q) * kqK, ke = min(KH, kb + kqK);
+            const int obi = tid >> 4, oej = tid & 15;
+            const int ob = jb0 + obi, oj = 16 * jt + oej;
+            const bool owner = tid < 256 && ob < B && oj < Hd;
+            Tile16Acc acc;
+            tile16_init(acc);
+            const float *wrow = ju < Hd ? a.W_ssT + (int64_t)ju * 4 * Hd : nullptr;
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                float4 wv[PD_KF];
+#pragma unroll
+                for (int fq = 0; fq < PD_KF; ++fq)
+                    wv[fq] = t16_load_fast(wrow ? wrow + c * KH : nullptr, kb + 4 * fq, ke, a.W_ssT);
+                int off[PD_KF];
+#pragma unroll
+                for (int fq = 0; fq < PD_KF; ++fq)
+                    off[fq] = (jrow < B && kb + 4 * fq < ke)
+                                  ? (p.o_drec + slot * NGR_R * 4 * B + (((c * KH + kb) >> 2) + fq) * 4 * B + 4 * jrow) * 4
+                                  : PD_OOB;
+                float4 av[PD_KF];
+                pd_gather<PD_KF>(av, rX, off, ep, PD_OOB, s_abort, p.err);   // published by now or within a spin or two: no probe
+#pragma unroll
+                for (int fq = 0; fq < PD_KF; ++fq) {
+                    acc.a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[fq].x, wv[fq].x, acc.a0, 0, 0, 0);
+                    acc.a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[fq].y, wv[fq].y, acc.a1, 0, 0, 0);
+                    acc.a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[fq].z, wv[fq].z, acc.a0, 0, 0, 0);
+                    acc.a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[fq].w, wv[fq].w, acc.a1, 0, 0, 0);
+                }
+            }
+            tile16_reduce(acc, red16b);
+            if (*s_abort) return;   // leaves the lambda; the caller's next barrier-side check leaves the kernel
+            if (tid < 256)
+                accW_reg = tile16_get(red16b, obi, oej) + (owner ? p.Q1[(int64_t)s * BH + (int64_t)ob * Hd + oj] : 0.f);
+    };
     for (int n = 0; n < L; ++n) {
         const int s = L - 1 - n;
         const int slot = n & 1, pslot = slot ^ 1;
@@ -2373,38 +2437,88 @@ __global__ __launch_bounds__(PD_THREADS) void attdec_bwd_persist_kernel(PBParams
                 }
             }
             PD_STAMP(2);
-            // ---- X2 (off the chain). drec_s W_ss + dyp_s W_sy for the next step's dS, kept in a register
-            if (n + 1 < L) {
-                Tile16Acc acc;
-                tile16_init(acc);
-                const float *wrow = ju < Hd ? a.W_ssT + (int64_t)ju * 4 * Hd : nullptr;
-#pragma unroll
-                for (int c = 0; c < 2; ++c) {
-                    float4 wv[PD_KF];
-#pragma unroll
-                    for (int fq = 0; fq < PD_KF; ++fq)
-                        wv[fq] = t16_load_fast(wrow ? wrow + c * KH : nullptr, kb + 4 * fq, ke, a.W_ssT);
-                    int off[PD_KF];
-#pragma unroll
-                    for (int fq = 0; fq < PD_KF; ++fq)
-                        off[fq] = (jrow < B && kb + 4 * fq < ke)
-                                      ? (p.o_drec + slot * NGR_R * 4 * B + (((c * KH + kb) >> 2) + fq) * 4 * B + 4 * jrow) * 4
-                                      : PD_OOB;
-                    float4 av[PD_KF];
-                    pd_gather<PD_KF>(av, rX, off, ep, off[0], s_abort, p.err);
-#pragma unroll
-                    for (int fq = 0; fq < PD_KF; ++fq) {
-                        acc.a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[fq].x, wv[fq].x, acc.a0, 0, 0, 0);
-                        acc.a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[fq].y, wv[fq].y, acc.a1, 0, 0, 0);
-                        acc.a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[fq].z, wv[fq].z, acc.a0, 0, 0, 0);
-                        acc.a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[fq].w, wv[fq].w, acc.a1, 0, 0, 0);
-                    }
-                }
-                tile16_reduce(acc, red16b);
-                if (*s_abort) return;
-                if (tid < 256)
-                    accW_reg = tile16_get(red16b, obi, oej) + (owner ? p.Q1[(int64_t)s * BH + (int64_t)ob * Hd + oj] : 0.f);
+        }
+        if (is_x && nrows == 0 && n + 1 < L) {
+            // not while the G jobs gather the same drec_s: the workgroup first waits (one wave, a granule per tile)
+            // until its utterance's <alpha, dalpha> partials exist -- the chain is two hand-offs further by then
+            if ((pd_opaque((int)threadIdx.x) >> 6) == 0) {
+                const int lane = pd_opaque((int)threadIdx.x) & 63;
+                const int off[1] = {lane < nact ? (p.o_dot + ((slot * B + b) * NTILE + lane) * 4) * 4 : PD_OOB};
+                float4 dv[1];
+                pd_gather<1>(dv, rX, off, ep, PD_OOB, s_abort, p.err);
             }
+            __syncthreads();
+            if (*s_abort) return;
+            do_x2(n, s, slot, ep);
+        }
+        if (nrows > 0) {
+            // ---- CV (off the chain). conv^T of the neighbours' dF_{s+1}; this step's alpha / conv features / sproj
+            {
+                const int tid = pd_opaque((int)threadIdx.x);
+                // all of this step's saved-tensor loads first (one memory round trip), the dF window gather behind them
+                const float alv = tid < nrows ? f.alpha[(int64_t)s * BT + (int64_t)b * T + t0 + tid] : 0.f;
+                float fsv[2];
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int i = tid + u * PD_THREADS, r = i / 12, c = i - 12 * r;
+                    fsv[u] = (i < TT * 12 && r < nrows && c < NCH) ? f.Fc[(((int64_t)s * B + b) * T + t0 + r) * NCH + c] : 0.f;
+                }
+                float4 spv = zero4();
+                if (4 * tid < A) spv = ld4(f.sproj + (int64_t)s * BA + (int64_t)b * A + 4 * tid);
+                float4 xv[1] = {zero4()};
+                if (n > 0 && (tid >> 6) * 64 < 163 * 3) {      // wave-uniform
+                    const int r = tid / 3, gq = tid - 3 * r;
+                    const int t = t0 - (KW - 1 - PADW) + r;
+                    const bool ok = tid < 163 * 3 && t >= 0 && t < len;
+                    const int off[1] = {ok ? (p.o_dF + ((pslot * B + b) * Tp + t) * 12 + 4 * gq) * 4 : PD_OOB};
+                    pd_gather<1>(xv, rX, off, pep, PD_OOB, s_abort, p.err);
+                }
+                if (tid < TT) altile[tid] = alv;
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+                    if (tid + u * PD_THREADS < TT * 12) m.Fs[tid + u * PD_THREADS] = fsv[u];
+                if (4 * tid < A)
+                    *reinterpret_cast<float4 *>(m.sp + 4 * tid) = make_float4(spv.x * K2L, spv.y * K2L, spv.z * K2L, spv.w * K2L);
+                if (n > 0 && tid < 163 * 3) *reinterpret_cast<float4 *>(xw + 4 * tid) = xv[0];
+            }
+            __syncthreads();
+            if (*s_abort) return;
+            if (n > 0) {
+                const int tid = pd_opaque((int)threadIdx.x);
+                const int lane = tid & 63, wave = tid >> 6, q = lane >> 4, col = lane & 15;
+                f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f}, acc3 = {0.f, 0.f, 0.f, 0.f};
+                const float *xa = xw + 192 * (col & 3) + q;
+                const float *kb_ = kfp + 180 - 12 * col + q;
+                const int ks0 = wave * 44;
+#pragma unroll
+                for (int u = 0; u < 44; u += 4) {
+                    float av[4], bv[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int ks = ks0 + u + e;
+                        av[e] = ks < PB_NKS ? xa[4 * ks] : 0.f;
+                        bv[e] = ks < PB_NKS ? kb_[4 * ks] : 0.f;
+                    }
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[0], bv[0], acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[1], bv[1], acc1, 0, 0, 0);
+                    acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[2], bv[2], acc2, 0, 0, 0);
+                    acc3 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[3], bv[3], acc3, 0, 0, 0);
+                }
+                acc0 += acc2;
+                acc1 += acc3;
+                if (lane < 16) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) dcvw[wave * TT + 16 * r + lane] = acc0[r] + acc1[r];
+                }
+                __syncthreads();
+                if (tid < TT) {
+                    float v = 0.f;
+#pragma unroll
+                    for (int wv = 0; wv < PD_WAVES; ++wv) v += dcvw[wv * TT + tid];
+                    dcv[tid] = v;
+                }
+            }
+            PD_STAMP(5);
         }
         // ---- G. one half of dg_s = drec_s W_gs + dyp_s W_gy for 16 rows x 16 columns
         if (is_g) {
@@ -2451,61 +2565,6 @@ __global__ __launch_bounds__(PD_THREADS) void attdec_bwd_persist_kernel(PBParams
             PD_STAMP(4);
         }
         if (nrows > 0) {
-            // ---- CV (off the chain). conv^T of the neighbours' dF_{s+1}; this step's alpha / conv features / sproj
-            {
-                const int tid = pd_opaque((int)threadIdx.x);
-                for (int i = tid; i < TT; i += PD_THREADS)
-                    altile[i] = i < nrows ? f.alpha[(int64_t)s * BT + (int64_t)b * T + t0 + i] : 0.f;
-                for (int i = tid; i < TT * 12; i += PD_THREADS) {
-                    const int r = i / 12, c = i - 12 * r;
-                    m.Fs[i] = (r < nrows && c < NCH) ? f.Fc[(((int64_t)s * B + b) * T + t0 + r) * NCH + c] : 0.f;
-                }
-                if (4 * tid < A) {
-                    const float4 v = ld4(f.sproj + (int64_t)s * BA + (int64_t)b * A + 4 * tid);
-                    *reinterpret_cast<float4 *>(m.sp + 4 * tid) = make_float4(v.x * K2L, v.y * K2L, v.z * K2L, v.w * K2L);
-                }
-                if (n > 0) {
-                    if ((tid >> 6) * 64 < 163 * 3) {      // wave-uniform
-                        const int r = tid / 3, gq = tid - 3 * r;
-                        const int t = t0 - (KW - 1 - PADW) + r;
-                        const bool ok = tid < 163 * 3 && t >= 0 && t < len;
-                        const int off[1] = {ok ? (p.o_dF + ((pslot * B + b) * Tp + t) * 12 + 4 * gq) * 4 : PD_OOB};
-                        float4 v[1];
-                        pd_gather<1>(v, rX, off, pep, PD_OOB, s_abort, p.err);
-                        if (tid < 163 * 3) *reinterpret_cast<float4 *>(xw + 4 * tid) = v[0];
-                    }
-                }
-            }
-            __syncthreads();
-            if (*s_abort) return;
-            if (n > 0) {
-                const int tid = pd_opaque((int)threadIdx.x);
-                const int lane = tid & 63, wave = tid >> 6, q = lane >> 4, col = lane & 15;
-                f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-                const float *xa = xw + 192 * (col & 3) + q;
-                const float *kb_ = kfp + 180 - 12 * col + q;
-                const int ks0 = wave * 44;
-#pragma unroll 4
-                for (int u = 0; u < 44; u += 2) {
-                    const int ka = ks0 + u, kc = ks0 + u + 1;
-                    const float a0 = ka < PB_NKS ? xa[4 * ka] : 0.f, b0 = ka < PB_NKS ? kb_[4 * ka] : 0.f;
-                    const float a1 = kc < PB_NKS ? xa[4 * kc] : 0.f, b1 = kc < PB_NKS ? kb_[4 * kc] : 0.f;
-                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b0, acc0, 0, 0, 0);
-                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b1, acc1, 0, 0, 0);
-                }
-                if (lane < 16) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) dcvw[wave * TT + 16 * r + lane] = acc0[r] + acc1[r];
-                }
-                __syncthreads();
-                if (tid < TT) {
-                    float v = 0.f;
-#pragma unroll
-                    for (int wv = 0; wv < PD_WAVES; ++wv) v += dcvw[wv * TT + tid];
-                    dcv[tid] = v;
-                }
-            }
-            PD_STAMP(5);
             // ---- DA. dg_s[b] (two partials), dalpha tile, <alpha, dalpha>, de
             {
                 const int tid = pd_opaque((int)threadIdx.x);
@@ -2578,7 +2637,8 @@ __global__ __launch_bounds__(PD_THREADS) void attdec_bwd_persist_kernel(PBParams
                     t.w4 = *reinterpret_cast<const float4 *>(m.wee + 16 * mt + 4 * q);
                     return t;
                 };
-                f32x4 dF0 = {0.f, 0.f, 0.f, 0.f}, dF1 = {0.f, 0.f, 0.f, 0.f};   // K2L * dF^T[c = 4q + r][t = col], partial over a
+                // K2L * dF^T[c = 4q + r][t = col], partial over a: four independent accumulation chains
+                f32x4 dF0 = {0.f, 0.f, 0.f, 0.f}, dF1 = {0.f, 0.f, 0.f, 0.f}, dF2 = {0.f, 0.f, 0.f, 0.f}, dF3 = {0.f, 0.f, 0.f, 0.f};
                 PBTile c0 = ldt(mt0), c1 = ldt(mt0 + 1);
 #pragma unroll
                 for (int j = 0; j < PD_MTP; j += 2) {
@@ -2606,11 +2666,14 @@ __global__ __launch_bounds__(PD_THREADS) void attdec_bwd_persist_kernel(PBParams
                     // dF^T[c][t] += sum_a W_fe[a][c] dpre[t][a]: k-step r pairs a = 16 mt + 4 q + r on both operands
                     const float *wc0 = m.wfe + (16 * (mt0 + j) + 4 * q) * 12 + col;
                     const float *wc1 = wc0 + 16 * 12;
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        dF0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wc0[r * 12], dp0[r], dF0, 0, 0, 0);
-                        dF1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wc1[r * 12], dp1[r], dF1, 0, 0, 0);
-                    }
+                    dF0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wc0[0], dp0[0], dF0, 0, 0, 0);
+                    dF1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wc1[0], dp1[0], dF1, 0, 0, 0);
+                    dF2 = __builtin_amdgcn_mfma_f32_16x16x4f32(wc0[12], dp0[1], dF2, 0, 0, 0);
+                    dF3 = __builtin_amdgcn_mfma_f32_16x16x4f32(wc1[12], dp1[1], dF3, 0, 0, 0);
+                    dF0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wc0[24], dp0[2], dF0, 0, 0, 0);
+                    dF1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wc1[24], dp1[2], dF1, 0, 0, 0);
+                    dF2 = __builtin_amdgcn_mfma_f32_16x16x4f32(wc0[36], dp0[3], dF2, 0, 0, 0);
+                    dF3 = __builtin_amdgcn_mfma_f32_16x16x4f32(wc1[36], dp1[3], dF3, 0, 0, 0);
                     const float t0_ = row16_sum4(dp0[0], dp0[1], dp0[2], dp0[3]);
                     const float t1_ = row16_sum4(dp1[0], dp1[1], dp1[2], dp1[3]);
                     if ((col & 3) == 0) {
@@ -2620,7 +2683,7 @@ __global__ __launch_bounds__(PD_THREADS) void attdec_bwd_persist_kernel(PBParams
                     c0 = n0; c1 = n1;
                 }
 #pragma unroll
-                for (int r = 0; r < 4; ++r) m.dFl[(part * TT + tl) * 16 + 4 * q + r] = dF0[r] + dF1[r];
+                for (int r = 0; r < 4; ++r) m.dFl[(part * TT + tl) * 16 + 4 * q + r] = (dF0[r] + dF1[r]) + (dF2[r] + dF3[r]);
                 __syncthreads();
                 // dsp partial of this tile (sum over its 4 x 16 frames), 16-byte tagged granules
                 if (4 * tid < A) {
@@ -2679,6 +2742,7 @@ __global__ __launch_bounds__(PD_THREADS) void attdec_bwd_persist_kernel(PBParams
                 *reinterpret_cast<float4 *>(a.dsp + (int64_t)s * BA + (int64_t)b * A + ca) = d4;
             }
         }
+        if (is_x && nrows > 0 && n + 1 < L) do_x2(n, s, slot, ep);
         PD_STAMP(9);
     }
 }
@@ -2795,7 +2859,7 @@ extern "C" int asr_attdec_bwd(const asr_attdec_bwd_args *a, void *stream) {
         const int64_t xfl = attdec_bwd_xch_floats(B, T, E, Hd);
         const size_t psm = attdec_bwd_persist_smem();
         if (attdec_persist_on() && use_v2 && vecH && vecT && A % 16 == 0 && E % 4 == 0 && nwg <= n_cu &&
-            (int64_t)(p.NJX + 2 * p.NJG) * p.MTB <= nwg && A16p <= PD_AL && p.ECG <= 4 * PD_HF && 2 * Hd <= 128 * PD_KF &&
+            (int64_t)(p.NJX + 2 * p.NJG) * p.MTB <= nwg && nwg <= PD_THREADS && A16p <= PD_AL && p.ECG <= 4 * PD_HF && 2 * Hd <= 128 * PD_KF &&
             p.ECH * 8 <= PD_AL && nt <= 8 && nt <= 64 && xfl * 4 < (int64_t)0x7fff0000 && psm <= 150 * 1024 &&
             al16(a->dg) && al16(a->dsp) && al16(a->ws) && al16(f->sproj)) {
             static thread_local bool attr3 = false;
