@@ -948,8 +948,10 @@ __global__ __launch_bounds__(PD_THREADS) void attdec_fwd_persist_kernel(PDParams
                 const int off[1] = {4 * tid < A ? ((pslot * B + b) * A16 + 4 * tid) * 4 : PD_OOB};
                 float4 v[1];
                 pd_gather<1>(v, rX, off, pep, PD_OOB, s_abort, p.err);
-                if (4 * tid < A)
-                    *reinterpret_cast<float4 *>(m.sp + 4 * tid) = make_float4(v[0].x * K2L, v[0].y * K2L, v[0].z * K2L, v[0].w * K2L);
+                if (4 * tid < A) {
+                    float *d = m.wfe + 4 * tid * 12 + 10;
+                    d[0] = v[0].x * K2L; d[12] = v[0].y * K2L; d[24] = v[0].z * K2L; d[36] = v[0].w * K2L;
+                }
             }
             for (int i = tid; i < TT + KW; i += PD_THREADS) {
                 const int t = t0 - PADW + i;
@@ -990,14 +992,14 @@ __global__ __launch_bounds__(PD_THREADS) void attdec_fwd_persist_kernel(PDParams
             float fB[3];
 #pragma unroll
             for (int ks = 0; ks < 3; ++ks) fB[ks] = m.Fs[tl * 12 + 4 * ks + q] + m.Fs[TT * 12 + tl * 12 + 4 * ks + q];
+            if (q == 2) fB[2] = 1.0f;     // k-slot 10 (ks = 2, q = 2) pairs with column 10 of the table: sproj rides there
             // PH (registers), sproj and W_fe (LDS) carry the factor 2 log2(e), so the MFMA result is the argument of
             // 2^x directly; sum_a w_a tanh(x_a) = sum_a w_a - 2 sum_a w_a / (1 + e^{2 x_a}): one FMA per element
             // No bounds: tiles past A read zero tables (w = 0) and zero PH.  Two tiles per round, the LDS operands of the
             // next round fetched before this round's arithmetic: two independent MFMA chains, eight independent 2^x / 1/x.
-            struct PDTile { float4 s4, w4; float a0, a1, a2; };
+            struct PDTile { float4 w4; float a0, a1, a2; };
             auto ldt = [&](int mt) {
                 PDTile t;
-                t.s4 = *reinterpret_cast<const float4 *>(m.sp + 16 * mt + 4 * q);
                 const float *wr = m.wfe + (16 * mt + col) * 12 + q;
                 t.a0 = wr[0]; t.a1 = wr[4]; t.a2 = wr[8];
                 t.w4 = *reinterpret_cast<const float4 *>(m.wee + 16 * mt + 4 * q);
@@ -1009,8 +1011,8 @@ __global__ __launch_bounds__(PD_THREADS) void attdec_fwd_persist_kernel(PDParams
             for (int j = 0; j < PD_MTP; j += 2) {
                 PDTile n0 = c0, n1 = c1;
                 if (j + 2 < PD_MTP) { n0 = ldt(mt0 + j + 2); n1 = ldt(mt0 + j + 3); }
-                f32x4 x0 = {phr[j].x + c0.s4.x, phr[j].y + c0.s4.y, phr[j].z + c0.s4.z, phr[j].w + c0.s4.w};
-                f32x4 x1 = {phr[j + 1].x + c1.s4.x, phr[j + 1].y + c1.s4.y, phr[j + 1].z + c1.s4.z, phr[j + 1].w + c1.s4.w};
+                f32x4 x0 = {phr[j].x, phr[j].y, phr[j].z, phr[j].w};
+                f32x4 x1 = {phr[j + 1].x, phr[j + 1].y, phr[j + 1].z, phr[j + 1].w};
                 x0 = __builtin_amdgcn_mfma_f32_16x16x4f32(c0.a0, fB[0], x0, 0, 0, 0);
                 x1 = __builtin_amdgcn_mfma_f32_16x16x4f32(c1.a0, fB[0], x1, 0, 0, 0);
                 x0 = __builtin_amdgcn_mfma_f32_16x16x4f32(c0.a1, fB[1], x0, 0, 0, 0);
@@ -2202,7 +2204,7 @@ struct PBParams {
 #define PB_NKS 345                // k-steps of the Toeplitz product: (180 + 1200) / 4
 
 static size_t attdec_bwd_persist_smem() {
-    return sizeof(float) * (size_t)(PD_AL * 14 + TT * 12 + PD_AL + 4 * TT + (PB_XW + 12) + PB_KF + PD_WAVES * TT +
+    return sizeof(float) * (size_t)(PD_AL * 25 + TT * 12 + PD_AL + 4 * TT + (PB_XW + 12) + PB_KF + PD_WAVES * TT +
                                     4 * PD_AL + 2 * TT * 16 + 2 * PD_WAVES * 16 * 17 + 8 * PD_AL / 8 + 64);
 }
 
@@ -2218,8 +2220,8 @@ __global__ __launch_bounds__(PD_THREADS) void attdec_bwd_persist_kernel(PBParams
     const int len = min(f.lengths[b], T);
     constexpr float K2L = 2.88539008177792681472f;
     E2Smem m;
-    m.sp = smem;                          // [PD_AL] K2L * sproj_s[b]
-    m.wfe = m.sp + PD_AL;                 // [PD_AL][12] K2L * W_fe
+    m.sp = smem;                          // [PD_AL][12] w_ee[a] * W_fe[a][c] (columns 10, 11 zero): A operand of the dF product
+    m.wfe = m.sp + PD_AL * 12;            // [PD_AL][12] K2L * {W_fe[a][0..9], sproj_s[b][a], 0}: the state projection rides in k-slot 10
     m.wee = m.wfe + PD_AL * 12;           // [PD_AL]
     m.Fs = m.wee + PD_AL;                 // [TT][12] saved conv features of this step
     float *dgs = m.Fs + TT * 12;          // [8 ECG <= PD_AL] dg_s[b]
@@ -2261,10 +2263,14 @@ __global__ __launch_bounds__(PD_THREADS) void attdec_bwd_persist_kernel(PBParams
         }
         __syncthreads();
     }
-    for (int i = tid; i < PD_AL * 12; i += PD_THREADS) m.wfe[i] = i < A16 * 12 ? p.tab[i] * K2L : 0.f;
+    for (int i = tid; i < PD_AL * 12; i += PD_THREADS) {
+        const int a_ = i / 12;
+        const float wf = i < A16 * 12 ? p.tab[i] : 0.f;
+        m.wfe[i] = wf * K2L;
+        m.sp[i] = a_ < A16 ? wf * p.tab[A16 * 12 + a_] : 0.f;
+    }
     for (int i = tid; i < PD_AL; i += PD_THREADS) {
         m.wee[i] = i < A16 ? p.tab[A16 * 12 + i] : 0.f;
-        m.sp[i] = 0.f;
         dgs[i] = 0.f;
     }
     for (int i = tid; i < PB_KF; i += PD_THREADS) {
@@ -2461,7 +2467,7 @@ __global__ __launch_bounds__(PD_THREADS) void attdec_bwd_persist_kernel(PBParams
 #pragma unroll
                 for (int u = 0; u < 2; ++u) {
                     const int i = tid + u * PD_THREADS, r = i / 12, c = i - 12 * r;
-                    fsv[u] = (i < TT * 12 && r < nrows && c < NCH) ? f.Fc[(((int64_t)s * B + b) * T + t0 + r) * NCH + c] : 0.f;
+                    fsv[u] = (i < TT * 12 && r < nrows && c < NCH) ? f.Fc[(((int64_t)s * B + b) * T + t0 + r) * NCH + c] : (c == NCH ? 1.0f : 0.f);
                 }
                 float4 spv = zero4();
                 if (4 * tid < A) spv = ld4(f.sproj + (int64_t)s * BA + (int64_t)b * A + 4 * tid);
@@ -2477,8 +2483,10 @@ __global__ __launch_bounds__(PD_THREADS) void attdec_bwd_persist_kernel(PBParams
 #pragma unroll
                 for (int u = 0; u < 2; ++u)
                     if (tid + u * PD_THREADS < TT * 12) m.Fs[tid + u * PD_THREADS] = fsv[u];
-                if (4 * tid < A)
-                    *reinterpret_cast<float4 *>(m.sp + 4 * tid) = make_float4(spv.x * K2L, spv.y * K2L, spv.z * K2L, spv.w * K2L);
+                if (4 * tid < A) {
+                    float *d = m.wfe + 4 * tid * 12 + 10;
+                    d[0] = spv.x * K2L; d[12] = spv.y * K2L; d[24] = spv.z * K2L; d[36] = spv.w * K2L;
+                }
                 if (n > 0 && tid < 163 * 3) *reinterpret_cast<float4 *>(xw + 4 * tid) = xv[0];
             }
             __syncthreads();
@@ -2628,43 +2636,41 @@ __global__ __launch_bounds__(PD_THREADS) void attdec_bwd_persist_kernel(PBParams
                 float fB[3];
 #pragma unroll
                 for (int ks = 0; ks < 3; ++ks) fB[ks] = m.Fs[tl * 12 + 4 * ks + q];
-                struct PBTile { float4 s4, w4; float a0, a1, a2; };
+                struct PBTile { float a0, a1, a2; };
                 auto ldt = [&](int mt) {
                     PBTile t;
-                    t.s4 = *reinterpret_cast<const float4 *>(m.sp + 16 * mt + 4 * q);
                     const float *wr = m.wfe + (16 * mt + col) * 12 + q;
                     t.a0 = wr[0]; t.a1 = wr[4]; t.a2 = wr[8];
-                    t.w4 = *reinterpret_cast<const float4 *>(m.wee + 16 * mt + 4 * q);
                     return t;
                 };
-                // K2L * dF^T[c = 4q + r][t = col], partial over a: four independent accumulation chains
+                // dF^T[c = 4q + r][t = col] / de-less form, partial over a: four independent accumulation chains
                 f32x4 dF0 = {0.f, 0.f, 0.f, 0.f}, dF1 = {0.f, 0.f, 0.f, 0.f}, dF2 = {0.f, 0.f, 0.f, 0.f}, dF3 = {0.f, 0.f, 0.f, 0.f};
                 PBTile c0 = ldt(mt0), c1 = ldt(mt0 + 1);
 #pragma unroll
                 for (int j = 0; j < PD_MTP; j += 2) {
                     PBTile n0 = c0, n1 = c1;
                     if (j + 2 < PD_MTP) { n0 = ldt(mt0 + j + 2); n1 = ldt(mt0 + j + 3); }
-                    f32x4 x0 = {phr[j].x + c0.s4.x, phr[j].y + c0.s4.y, phr[j].z + c0.s4.z, phr[j].w + c0.s4.w};
-                    f32x4 x1 = {phr[j + 1].x + c1.s4.x, phr[j + 1].y + c1.s4.y, phr[j + 1].z + c1.s4.z, phr[j + 1].w + c1.s4.w};
+                    // x = K2L (PH + sproj + F W_fe^T): PH is the accumulator input, sproj k-slot 10 (F[t][10] = 1)
+                    f32x4 x0 = {phr[j].x, phr[j].y, phr[j].z, phr[j].w};
+                    f32x4 x1 = {phr[j + 1].x, phr[j + 1].y, phr[j + 1].z, phr[j + 1].w};
                     x0 = __builtin_amdgcn_mfma_f32_16x16x4f32(c0.a0, fB[0], x0, 0, 0, 0);
                     x1 = __builtin_amdgcn_mfma_f32_16x16x4f32(c1.a0, fB[0], x1, 0, 0, 0);
                     x0 = __builtin_amdgcn_mfma_f32_16x16x4f32(c0.a1, fB[1], x0, 0, 0, 0);
                     x1 = __builtin_amdgcn_mfma_f32_16x16x4f32(c1.a1, fB[1], x1, 0, 0, 0);
                     x0 = __builtin_amdgcn_mfma_f32_16x16x4f32(c0.a2, fB[2], x0, 0, 0, 0);
                     x1 = __builtin_amdgcn_mfma_f32_16x16x4f32(c1.a2, fB[2], x1, 0, 0, 0);
-                    // sech^2 = 4 E / (1 + E)^2, E = 2^(-|x|) (x carries the factor 2 log2 e); the 4 rides in de4
+                    // sech^2 / 4 = E / (1 + E)^2 = r (1 - r), r = 1 / (1 + E), E = 2^(-|x|); the 4 rides in de4 and w_ee[a]
+                    // in the dF operand table and in the final dsp sum: two transcendentals + three VALU per element
                     float dp0[4], dp1[4];
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const float e0 = __builtin_amdgcn_exp2f(-fabsf(x0[r])), e1 = __builtin_amdgcn_exp2f(-fabsf(x1[r]));
-                        const float r0 = __builtin_amdgcn_rcpf(1.0f + e0), r1 = __builtin_amdgcn_rcpf(1.0f + e1);
-                        dp0[r] = e0 * r0 * r0;
-                        dp1[r] = e1 * r1 * r1;
+                        const float r0 = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-fabsf(x0[r])));
+                        const float r1 = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-fabsf(x1[r])));
+                        dp0[r] = de4 * __builtin_fmaf(-r0, r0, r0);
+                        dp1[r] = de4 * __builtin_fmaf(-r1, r1, r1);
                     }
-                    dp0[0] *= de4 * c0.w4.x; dp0[1] *= de4 * c0.w4.y; dp0[2] *= de4 * c0.w4.z; dp0[3] *= de4 * c0.w4.w;
-                    dp1[0] *= de4 * c1.w4.x; dp1[1] *= de4 * c1.w4.y; dp1[2] *= de4 * c1.w4.z; dp1[3] *= de4 * c1.w4.w;
-                    // dF^T[c][t] += sum_a W_fe[a][c] dpre[t][a]: k-step r pairs a = 16 mt + 4 q + r on both operands
-                    const float *wc0 = m.wfe + (16 * (mt0 + j) + 4 * q) * 12 + col;
+                    // dF^T[c][t] += sum_a (w_a W_fe[a][c]) dp[a][t]: k-step r pairs a = 16 mt + 4 q + r on both operands
+                    const float *wc0 = m.sp + (16 * (mt0 + j) + 4 * q) * 12 + col;
                     const float *wc1 = wc0 + 16 * 12;
                     dF0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wc0[0], dp0[0], dF0, 0, 0, 0);
                     dF1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wc1[0], dp1[0], dF1, 0, 0, 0);
@@ -2691,20 +2697,20 @@ __global__ __launch_bounds__(PD_THREADS) void attdec_bwd_persist_kernel(PBParams
                     const float4 u1 = *reinterpret_cast<const float4 *>(m.dspl + PD_AL + 4 * tid);
                     const float4 u2 = *reinterpret_cast<const float4 *>(m.dspl + 2 * PD_AL + 4 * tid);
                     const float4 u3 = *reinterpret_cast<const float4 *>(m.dspl + 3 * PD_AL + 4 * tid);
+                    const float4 w4 = *reinterpret_cast<const float4 *>(m.wee + 4 * tid);
                     pd_st4_tag(rX, (p.o_dspp + ((slot * B + b) * NTILE + k) * A16 + 4 * tid) * 4,
-                               make_float4((u0.x + u1.x) + (u2.x + u3.x), (u0.y + u1.y) + (u2.y + u3.y),
-                                           (u0.z + u1.z) + (u2.z + u3.z), (u0.w + u1.w) + (u2.w + u3.w)), ep);
+                               make_float4(w4.x * ((u0.x + u1.x) + (u2.x + u3.x)), w4.y * ((u0.y + u1.y) + (u2.y + u3.y)),
+                                           w4.z * ((u0.z + u1.z) + (u2.z + u3.z)), w4.w * ((u0.w + u1.w) + (u2.w + u3.w))), ep);
                 }
                 // dF tile: published for the neighbours' conv^T of the next step (12 floats a frame) and saved
                 if (tid < 3 * TT) {
                     const int r = tid / 3, gq = tid - 3 * r;
                     if (r < nrows) {
-                        constexpr float IK = 1.0f / K2L;
                         float v[4];
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
                             const int c = 4 * gq + e;
-                            v[e] = c < NCH ? (m.dFl[r * 16 + c] + m.dFl[(TT + r) * 16 + c]) * IK : 0.f;
+                            v[e] = c < NCH ? m.dFl[r * 16 + c] + m.dFl[(TT + r) * 16 + c] : 0.f;
                         }
                         pd_st4_tag(rX, (p.o_dF + ((slot * B + b) * Tp + t0 + r) * 12 + 4 * gq) * 4,
                                    make_float4(v[0], v[1], v[2], v[3]), ep);
