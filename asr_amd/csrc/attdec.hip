@@ -2205,7 +2205,7 @@ struct PBParams {
 
 static size_t attdec_bwd_persist_smem() {
     return sizeof(float) * (size_t)(PD_AL * 25 + TT * 12 + PD_AL + 4 * TT + (PB_XW + 12) + PB_KF + PD_WAVES * TT +
-                                    4 * PD_AL + 2 * TT * 16 + 2 * PD_WAVES * 16 * 17 + 8 * PD_AL / 8 + 64);
+                                    4 * PD_AL + 2 * TT * 16 + 2 * PD_WAVES * 16 * 17 + 2 * PD_AL + 64);
 }
 
 __global__ __launch_bounds__(PD_THREADS) void attdec_bwd_persist_kernel(PBParams p) {
@@ -2236,8 +2236,8 @@ __global__ __launch_bounds__(PD_THREADS) void attdec_bwd_persist_kernel(PBParams
     m.dFl = m.dspl + 4 * PD_AL;           // [2][TT][16]
     float (*red16)[16][17] = reinterpret_cast<float (*)[16][17]>(m.dFl + 2 * TT * 16);                    // X, G
     float (*red16b)[16][17] = reinterpret_cast<float (*)[16][17]>(m.dFl + 2 * TT * 16 + PD_WAVES * 16 * 17);  // X2
-    float *rbuf = m.dFl + 2 * TT * 16 + 2 * PD_WAVES * 16 * 17;     // [8][ECH <= PD_AL / 8]
-    float *sred = rbuf + PD_AL;           // [32]
+    float *rbuf = m.dFl + 2 * TT * 16 + 2 * PD_WAVES * 16 * 17;     // [NTILE][ECH]: NTILE * ECH <= 2 PD_AL
+    float *sred = rbuf + 2 * PD_AL;       // [32]
     int *s_abort = reinterpret_cast<int *>(sred + 32);
     float *sdot = sred + 34;
 
@@ -2866,7 +2866,7 @@ extern "C" int asr_attdec_bwd(const asr_attdec_bwd_args *a, void *stream) {
         const size_t psm = attdec_bwd_persist_smem();
         if (attdec_persist_on() && use_v2 && vecH && vecT && A % 16 == 0 && E % 4 == 0 && nwg <= n_cu &&
             (int64_t)(p.NJX + 2 * p.NJG) * p.MTB <= nwg && nwg <= PD_THREADS && A16p <= PD_AL && p.ECG <= 4 * PD_HF && 2 * Hd <= 128 * PD_KF &&
-            p.ECH * 8 <= PD_AL && nt <= 8 && nt <= 64 && xfl * 4 < (int64_t)0x7fff0000 && psm <= 150 * 1024 &&
+            nt * p.ECH <= 2 * PD_AL && nt * (p.ECH / 4) <= PD_THREADS && nt <= 64 && xfl * 4 < (int64_t)0x7fff0000 && psm <= 150 * 1024 &&
             al16(a->dg) && al16(a->dsp) && al16(a->ws) && al16(f->sproj)) {
             static thread_local bool attr3 = false;
             if (!attr3) {

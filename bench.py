@@ -33,12 +33,16 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
 MFMA_F32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: fp32-input MFMA = vector peak
+MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16 MFMA (the headline figure with 2:1 sparsity is not used)
 XGMI_LINK_GBS = 153.0          # one xGMI link (7 per GPU)
 # HBM-side bytes per launch from the rocprofv3 PMC passes kept under profiles/ (FETCH_SIZE x 2: the gfx950
 # correction for 16-byte streams of MI355X_MICROARCH.md, + WRITE_SIZE), same kernels and shapes as here
-PMC_TRAFFIC = {
-    "blstm_fwd": 2 * 486757e3 + 280000e3,          # profiles/r1_pmc_blstm.txt
-    "blstm_bwd": 2 * 1.989e9 + 1.757e9,            # profiles/r1_pmc_blstm.txt
+PMC_TRAFFIC = {                                      # profiles/r2_pmc_fetch_write.txt
+    "blstm_fwd": 2 * 486742e3 + 280000e3,
+    "blstm_bwd": 2 * 595221e3 + 958400e3,
+    "attdec_fwd": 2 * 180997e3 + 166028e3,
+    "attdec_bwd": 2 * 394285e3 + 249210e3,
+    "ls_ce_config4": 2 * 66465e3 + 131470e3,
 }
 
 
@@ -213,9 +217,14 @@ def roofline_probe(hp, dev, in_step=None):
     Cm = torch.empty(M, N, device=dev)
     dt = time_kernel_events(lambda: ops.sgemm(A, Wp, Cm, M, N, K, a_stride=K, b_stride=K, c_stride=N), 20)
     flops = 2.0 * M * N * K
-    out["sgemm_proj"] = {"bound": "mfma", "achieved": flops / dt / 1e12, "peak": MFMA_F32_PEAK_TFLOPS,
-                         "unit": "TFLOP/s", "frac": flops / dt / 1e12 / MFMA_F32_PEAK_TFLOPS, "traffic": None,
-                         "kernel": "sgemm_kernel<128,64,32,0,0,true>", "shape": [M, N, K], "avg_us": dt * 1e6}
+    # the default arithmetic of the BLSTM path's hoisted products is the bf16x3 split (three bf16 MFMA products per
+    # fp32 product, fp32 accumulate: asr_gemm_precision): priced against the dense bf16 MFMA peak with the three
+    # products counted; `fp32_equivalent_tflops` is 2 M N K / time
+    out["sgemm_proj"] = {"bound": "mfma", "achieved": 3.0 * flops / dt / 1e12, "peak": MFMA_BF16_PEAK_TFLOPS,
+                         "unit": "TFLOP/s", "frac": 3.0 * flops / dt / 1e12 / MFMA_BF16_PEAK_TFLOPS, "traffic": None,
+                         "kernel": "sgemm_bf_kernel<128,128,0,0,3> (bf16x3 split)", "shape": [M, N, K],
+                         "avg_us": dt * 1e6, "fp32_equivalent_tflops": flops / dt / 1e12,
+                         "fp32_equivalent_frac_of_fp32_mfma_peak": flops / dt / 1e12 / MFMA_F32_PEAK_TFLOPS}
     # (3) fused label-smoothed CE: logits read once + gradient written once
     Bq, L, V = 32, 100, hp.num_classes
     z = torch.randn(Bq, L, V, generator=g).to(dev)
@@ -233,6 +242,54 @@ def roofline_probe(hp, dev, in_step=None):
     out["ls_ce"] = {"bound": "hbm", "achieved": nbytes / dt / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": nbytes / dt / 1e9 / HBM_PEAK_GBS, "traffic": None,
                     "kernel": "ls_ce_kernel<1> + ls_sum_kernel", "shape": [Bq, L, V], "avg_us": dt * 1e6}
+    # (3b) the same at the config-4 (CSJ, 7k BPE) shape, where the loss is a real HBM stream
+    Bq, L, V = 32, 150, 7000
+    z = torch.randn(Bq, L, V, generator=g).to(dev)
+    tg = torch.randint(0, V, (Bq, L), generator=g).to(dev)
+    tl = torch.full((Bq,), L, dtype=torch.int64, device=dev)
+    row = torch.empty(Bq * L, device=dev)
+    dz = torch.empty_like(z)
+    dt = time_kernel_events(loss_k, 20)
+    nbytes = 2.0 * Bq * L * V * 4
+    out["ls_ce_config4"] = {"bound": "hbm", "achieved": nbytes / dt / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                            "frac": nbytes / dt / 1e9 / HBM_PEAK_GBS, "traffic": PMC_TRAFFIC.get("ls_ce_config4"),
+                            "kernel": "ls_ce_kernel<8> + ls_sum_kernel", "shape": [Bq, L, V], "avg_us": dt * 1e6}
+    del z, dz
+    # (4) the attention decoder loop: one persistent launch per pass (csrc/attdec.hip).  PH and hbatch are read ONCE
+    # per launch and stay in registers for all L steps, so the algorithmic HBM bytes are the saved activations; the
+    # kernels are bound by the hand-off latency of the 4-5 dependent edges per label step and by transcendental
+    # issue (tanh / sech^2 of B T A elements per step), not by HBM -- the fraction says so
+    from asr_amd.Models.decoder import Decoder
+    Bq, T, L, V, Hd, E = 32, 500, 100, hp.num_classes, hp.num_hidden_nodes_decoder, 2 * hp.num_hidden_nodes_encoder
+    A = 2 * Hd
+    torch.manual_seed(0)
+    dec = Decoder(hp).to(dev).train()
+    lens = torch.linspace(500, 300, Bq).long()
+    hb = torch.randn(Bq, T, E, generator=g).to(dev)
+    for b in range(Bq):
+        hb[b, lens[b]:] = 0
+    tgt = torch.randint(0, V, (Bq, L), generator=g).to(dev)
+    wy = torch.randn(Bq, L, V, generator=g).to(dev)
+    kt = KernelTimer(("asr_attdec_fwd", "asr_attdec_bwd"))
+    for _ in range(4):
+        dec.zero_grad(set_to_none=True)
+        hd = hb.clone().requires_grad_(True)
+        (dec(hd, lens, tgt) * wy).sum().backward()
+    torch.cuda.synchronize()
+    tdec = kt.finish()
+    vf = float(lens.sum())
+    fwd_bytes = 4.0 * (2 * vf * A + L * Bq * T + L * vf * 10 + L * Bq * (E + 2 * Hd + 4 * Hd + A))
+    bwd_bytes = 4.0 * (2 * vf * A + L * Bq * T + L * vf * 10 + L * Bq * (A + 4 * Hd + Hd + Hd + E)
+                       + L * Bq * (4 * Hd + A + E) + L * vf * 11)
+    for key, name, nb in (("attdec_fwd", "asr_attdec_fwd", fwd_bytes), ("attdec_bwd", "asr_attdec_bwd", bwd_bytes)):
+        dt = tdec[name]
+        out[key] = {"bound": "hbm", "achieved": nb / dt / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": nb / dt / 1e9 / HBM_PEAK_GBS, "traffic": PMC_TRAFFIC.get(key),
+                    "kernel": key + "_persist_kernel (whole L-step loop" + (", hoisted dyp GEMMs and phase 2 included)"
+                                                                            if key == "attdec_bwd" else ")"),
+                    "shape": [Bq, T, L, A], "avg_us": dt * 1e6, "us_per_label_step": dt * 1e6 / L,
+                    "note": "latency / transcendental-issue bound: PH and hbatch are register-resident, "
+                            "HBM carries only the saved activations"}
     return out
 
 

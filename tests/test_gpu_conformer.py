@@ -331,3 +331,72 @@ def test_eval_mode_backward_vs_oracle():
     for k, v in m.state_dict().items():               # eval mode leaves the buffers alone
         if "running_" in k:
             assert torch.equal(v.cpu(), state[k]), k
+
+
+def test_full_size_config5_properties():
+    """BASELINE config 5 at full size (the model bench.py's `config5_conformer` times: AttModel(encoder_type=
+    'Conformer') = 16 layers, d_model 256, 4 heads, 48 M parameters; B=32, 1500 mel frames -> T'=374, V=1000,
+    L=100, dropout 0.1 as the reference trains): far too slow for the CPU restatement, so -- like
+    test_full_size_properties for configs 2 and 4 -- size-independent properties: finite loss and gradients for every
+    parameter, and the derivative of the loss along a random parameter direction against a central finite difference.
+    The dropout masks are drawn from torch's CPU generator (one seed per site), so re-seeding it before every pass
+    makes the training-mode passes evaluate the same function.  The direction leaves out the two Conv2d weights of
+    the subsampling: their gradient elements are sums over 227 392 patch rows with random signs, whose fp32
+    round-off alone moves the directional derivative by ~10 % (tools/cnn_check.py: against a float64 torch
+    reference the kernels' conv.2.weight gradient is within 1.7e-3 of the largest element -- closer than torch's own
+    fp32 convolution backward, 4.5e-3 -- and tools/fd_config5.py shows every other parameter group converging to
+    the analytic value); they are covered by the golden cases and by tools/cnn_check.py instead."""
+    import types
+    from asr_amd.Loss.label_smoothing import label_smoothing_loss
+    from asr_amd.Models.AttModel import AttModel
+    dev = _dev()
+    B, Tm, V, L = 32, 1500, 1000, 100
+    hp = types.SimpleNamespace(lmfb_dim=80, frame_stacking=1, num_hidden_nodes=320, num_hidden_nodes_encoder=256,
+                               num_hidden_nodes_decoder=320, num_encoder_layer=5, encoder_dropout=0.2,
+                               encoder_type="Conformer", decoder_type="Attention", num_classes=V, eos_id=1,
+                               T_norm=True, B_norm=False, beam_width=1, max_decoder_seq_len=200,
+                               score_func="log_softmax")
+    torch.manual_seed(1234)
+    m = AttModel(hp).to(dev).train()
+    assert sum(p.numel() for p in m.parameters()) > 40e6
+    g = torch.Generator().manual_seed(1234)
+    lens = torch.linspace(1500, 900, B).long()
+    x = torch.randn(B, Tm, 80, generator=g)
+    src_pos = torch.zeros(B, Tm, dtype=torch.int64)
+    for b in range(B):
+        x[b, lens[b]:] = 0
+        src_pos[b, :lens[b]] = torch.arange(1, int(lens[b]) + 1)
+    tl = torch.linspace(100, 50, B).long()
+    tgt = torch.randint(0, V, (B, L), generator=g)
+    for b in range(B):
+        tgt[b, tl[b]:] = 0
+    x, src_pos, tgt, tl_d = x.to(dev), src_pos.to(dev), tgt.to(dev), tl.to(dev)
+
+    def loss_of():
+        torch.manual_seed(99)          # same dropout masks in every pass
+        return label_smoothing_loss(m(x, lens, tgt, src_pos), tgt, tl_d, hp.T_norm, hp.B_norm)
+
+    loss = loss_of()
+    loss.backward()
+    assert torch.isfinite(loss)
+    for k, p in m.named_parameters():
+        assert p.grad is not None and torch.isfinite(p.grad).all(), k
+    with torch.no_grad():
+        torch.manual_seed(7)
+        dirs = {k: (torch.zeros_like(p) if k in ("encoder.cnn_encoder.conv.0.weight", "encoder.cnn_encoder.conv.2.weight")
+                    else torch.randn_like(p)) for k, p in m.named_parameters()}
+        analytic = sum(float((p.grad.double() * dirs[k].double()).sum()) for k, p in m.named_parameters())
+        # 48 M parameters all move at once: the step must be small for the loss to be quadratic along it (the
+        # central difference at 1e-3 is 14 % off, at 2.5e-4 1 %); two steps, Richardson-extrapolated
+        fds = []
+        for eps in (5e-4, 2.5e-4):
+            vals = []
+            for sgn in (+1, -1):
+                for k, p in m.named_parameters():
+                    p.add_(dirs[k], alpha=sgn * eps)
+                vals.append(float(loss_of()))
+                for k, p in m.named_parameters():
+                    p.add_(dirs[k], alpha=-sgn * eps)
+            fds.append((vals[0] - vals[1]) / (2 * eps))
+        fd = fds[1] + (fds[1] - fds[0]) / 3.0
+    assert abs(fd - analytic) / max(abs(analytic), 1e-6) < 3e-2, (fds, fd, analytic)

@@ -948,6 +948,7 @@ def test_attmodel_gemm_precision_modes(mode, loss_tol, out_tol, grad_tol):
 
 
 @pytest.mark.parametrize("B,T,He,Hd,V,L,lens", [(32, 500, 320, 320, 1000, 12, "ragged"), (5, 130, 16, 8, 11, 6, [130, 64, 65, 1, 100]),
+                                                (32, 374, 128, 320, 1000, 7, "ragged"),      # config-5 decoder: E = 256
                                                 (18, 70, 8, 16, 9, 4, None), (3, 17, 4, 8, 7, 5, [17, 9, 4])])
 def test_decoder_persistent_loop_vs_per_step_launches(B, T, He, Hd, V, L, lens):
     """The one-launch decoder loop (in-launch hand-offs between workgroups) against the four-launches-per-step
@@ -962,7 +963,7 @@ def test_decoder_persistent_loop_vs_per_step_launches(B, T, He, Hd, V, L, lens):
     torch.manual_seed(T + Hd)
     dec = Decoder(hp).to(dev).train()
     if lens == "ragged":
-        lengths = torch.linspace(T, 300, B).long()
+        lengths = torch.linspace(T, int(0.6 * T), B).long()
     else:
         lengths = torch.tensor(lens) if lens is not None else torch.randint(1, T + 1, (B,))
     h = torch.randn(B, T, 2 * He)
