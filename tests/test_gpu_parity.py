@@ -949,6 +949,8 @@ def test_attmodel_gemm_precision_modes(mode, loss_tol, out_tol, grad_tol):
 
 @pytest.mark.parametrize("B,T,He,Hd,V,L,lens", [(32, 500, 320, 320, 1000, 12, "ragged"), (5, 130, 16, 8, 11, 6, [130, 64, 65, 1, 100]),
                                                 (32, 374, 128, 320, 1000, 7, "ragged"),      # config-5 decoder: E = 256
+                                                (32, 448, 320, 320, 1000, 5, "full"),        # no empty tile: X jobs on loaded tiles
+                                                (16, 512, 320, 320, 1000, 4, "full"),        # one batch tile, T a multiple of 64
                                                 (18, 70, 8, 16, 9, 4, None), (3, 17, 4, 8, 7, 5, [17, 9, 4])])
 def test_decoder_persistent_loop_vs_per_step_launches(B, T, He, Hd, V, L, lens):
     """The one-launch decoder loop (in-launch hand-offs between workgroups) against the four-launches-per-step
@@ -962,7 +964,9 @@ def test_decoder_persistent_loop_vs_per_step_launches(B, T, He, Hd, V, L, lens):
     hp = R.make_hp(num_hidden_nodes_encoder=He, num_hidden_nodes_decoder=Hd, num_classes=V)
     torch.manual_seed(T + Hd)
     dec = Decoder(hp).to(dev).train()
-    if lens == "ragged":
+    if lens == "full":
+        lengths = torch.full((B,), T, dtype=torch.int64)
+    elif lens == "ragged":
         lengths = torch.linspace(T, int(0.6 * T), B).long()
     else:
         lengths = torch.tensor(lens) if lens is not None else torch.randint(1, T + 1, (B,))
