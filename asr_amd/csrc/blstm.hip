@@ -186,6 +186,8 @@ static int blstm_bwd_steps(const float *W_hhT, float *G, const float *Cs, const 
 // same way, so the grid always drains.
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 #define SPIN_LIMIT (1 << 21)
+#define BLSTM_PACE_START 8     // initial wait before a step's first exchange gather, units of s_sleep 2
+#define BLSTM_PACE_MAX 40
 #define OOB_OFF 0x7ffffff0   // beyond every buffer here: the range check returns zeros
 
 __device__ __forceinline__ float4 ld4_sc1(__amdgpu_buffer_rsrc_t rsrc, int byte_off) {
@@ -395,6 +397,7 @@ __global__ __launch_bounds__(256) void blstm_fwd_persist_kernel(
         }
     };
 
+    int pace = BLSTM_PACE_START, calm = 0;     // paced first attempt of the exchange gather, see the loop
     int s = s0;
     if (s == 0) {   // first step of the layer: no recurrent term, nothing pending
         const int t = d == 0 ? 0 : T - 1;
@@ -432,6 +435,14 @@ __global__ __launch_bounds__(256) void blstm_fwd_persist_kernel(
         float4 a[MT][NA];
         float pre[4];
         bool ok = true;
+        // Paced first attempt.  A gather issued the moment the step starts goes out ~0.6 us before the last producer's
+        // h is visible, and a failed attempt costs a whole extra round trip (0.7 us); waiting first and reading once is
+        // cheaper (forward 2.39 -> 2.05, backward 2.25 -> 2.07 us per step at H = 320 with the best fixed wait: 12 and 4
+        // units).  The wait adapts per wave: every 16 steps it grows by one unit if 5 or more first attempts failed and
+        // shrinks by one if at most 1 did (unit = s_sleep 2 = 128 cycles).  Only timing
+        // depends on it: an early attempt still falls into the retry loop below.
+        if (!(dbg & 4))
+            for (int w_ = 0; w_ < pace; ++w_) __builtin_amdgcn_s_sleep(2);
 #pragma unroll
         for (int m = 0; m < MT; ++m)
 #pragma unroll
@@ -450,6 +461,14 @@ __global__ __launch_bounds__(256) void blstm_fwd_persist_kernel(
 #pragma unroll
             for (int f = 0; f < NA; ++f) ok = ok & (tags_ok(a[m][f], want) | (kof(f) >= H));
         if (tagmode && !(dbg & 1)) {
+            {
+                calm += __all(ok) ? 0 : 0x100;                 // high byte: failed first attempts of this window
+                if ((++calm & 0xff) == 16) {                   // every 16 steps: aim at 2..4 failures per window
+                    const int fails = calm >> 8;
+                    pace = fails >= 3 ? min(pace + 1, BLSTM_PACE_MAX) : (fails == 0 ? max(pace - 1, 0) : pace);
+                    calm = 0;
+                }
+            }
             for (int spins = 0; !__all(ok); ++spins) {   // wave-uniform
                 if (spins >= SPIN_LIMIT) {
                     if (lane == 0) {
@@ -842,6 +861,7 @@ __global__ __launch_bounds__(256) void blstm_bwd_rs_kernel(
         return (valid && t < len) ? (int)(((((int64_t)t * B + b) * 2 + d) * 4 * H + j) * 4) : OOB_OFF;
     };
 
+    int pace = BLSTM_PACE_START, calm = 0;     // paced first attempt of the exchange gather
     int s = s0;
     if (s == 0) {   // first step: nothing to receive, nothing pending
         const int t = d == 0 ? T - 1 : 0;
@@ -882,6 +902,8 @@ __global__ __launch_bounds__(256) void blstm_bwd_rs_kernel(
         const int off0 = (int)((((s - 1) & 1) * slotf + ((int64_t)(jj >> 4) * 16 + ib) * 16 + (jj & 15)) * 4);
         const unsigned want = (unsigned)(((s - 1) >> 1) & 1);
         float4 v[CH];
+        if (!(dbg & 4))      // paced first attempt, as in the forward kernel
+            for (int w_ = 0; w_ < pace; ++w_) __builtin_amdgcn_s_sleep(2);
 #pragma unroll
         for (int c = 0; c < CH; ++c) {
             const int w = grp + c * NG;
@@ -895,6 +917,14 @@ __global__ __launch_bounds__(256) void blstm_bwd_rs_kernel(
 #pragma unroll
         for (int c = 0; c < CH; ++c) ok = ok & (tags_ok(v[c], want) | (grp + c * NG >= NJT));
         if (tagmode && !(dbg & 1)) {
+            {
+                calm += __all(ok) ? 0 : 0x100;                 // high byte: failed first attempts of this window
+                if ((++calm & 0xff) == 16) {                   // every 16 steps: aim at 2..4 failures per window
+                    const int fails = calm >> 8;
+                    pace = fails >= 3 ? min(pace + 1, BLSTM_PACE_MAX) : (fails == 0 ? max(pace - 1, 0) : pace);
+                    calm = 0;
+                }
+            }
             for (int spins = 0; !__all(ok); ++spins) {   // wave-uniform
                 if (spins >= SPIN_LIMIT) {
                     if (lane == 0) {
