@@ -34,6 +34,7 @@ class GemmDesc(C.Structure):
         ("c_keep", c_f), ("c_keep_scale", C.c_float),
         ("batch_d", C.c_int), ("batch_a1", c_i64), ("batch_b1", c_i64), ("batch_c1", c_i64),
         ("pad_ok", C.c_int),
+        ("a_span", c_i64), ("b_span", c_i64),
     ]
 
 

@@ -368,7 +368,7 @@ __device__ __forceinline__ void store_tile_bf(unsigned (*hi)[R + GPAD(MODE)], un
 }
 
 template <int BM, int BN, int AMODE, int BMODE, int NPROD, bool KLIST = false>
-__global__ __launch_bounds__(256) void sgemm_bf_kernel(asr_gemm_desc d, int ktiles_per_split) {
+__global__ __launch_bounds__(256) void sgemm_bf_kernel(asr_gemm_desc d, int ktiles_per_split, int xcd_map) {
     constexpr int GK = BF_GK;
     constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
     constexpr int LO = NPROD > 1 ? 2 : 1;     // the lo images only exist for the split
@@ -379,7 +379,18 @@ __global__ __launch_bounds__(256) void sgemm_bf_kernel(asr_gemm_desc d, int ktil
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
-    const int n0 = blockIdx.x * BN, m0 = blockIdx.y * BM;
+    // Workgroups are handed to the 8 XCDs round-robin by their linear id; each XCD has its own L2.  Renumber the
+    // tiles of a z-slice so that XCD x works through one contiguous run of the (row-major, N fastest) tile order:
+    // a row tile of A then lives in ONE L2 instead of being fetched by all eight.
+    int bx = blockIdx.x, by = blockIdx.y;
+    if (xcd_map & 1) {
+        const int nt = gridDim.x * gridDim.y, id = by * gridDim.x + bx;
+        const int q = nt >> 3, r = nt & 7, x = id & 7, loc = id >> 3;
+        const int tile = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + loc;
+        by = tile / gridDim.x;
+        bx = tile - by * gridDim.x;
+    }
+    const int n0 = bx * BN, m0 = by * BM;
     const int batch = blockIdx.z / d.splitk, split = blockIdx.z % d.splitk;
     const int bhi = d.batch_d > 0 ? batch / d.batch_d : 0, blo = batch - bhi * (d.batch_d > 0 ? d.batch_d : 0);
     OperandView va{d.A + (int64_t)blo * d.batch_a + (int64_t)bhi * d.batch_a1, d.a_mode, d.a_s0, d.a_s1, d.a_d};
@@ -421,11 +432,12 @@ __global__ __launch_bounds__(256) void sgemm_bf_kernel(asr_gemm_desc d, int ktil
     int cur = 0;
     for (int kt = 0; kt < nk; ++kt) {
         const bool more = kt + 1 < nk;
-        if (more) {
+        if (more && !(xcd_map & 2)) {
             la.load(va, d.M, kbeg + (kt + 1) * GK, kend, 1, ra, kidx, klast);
             lb.load(vb, d.N, kbeg + (kt + 1) * GK, kend, 1, rb, kidx, klast);
         }
         const int lcur = NPROD > 1 ? cur : 0;
+        if (!(xcd_map & 8))
 #pragma unroll
         for (int ks = 0; ks < GK / 16; ++ks) {
             u32x4g ah[TM], al[TM], bh[TN], bl[TN];
@@ -456,7 +468,7 @@ __global__ __launch_bounds__(256) void sgemm_bf_kernel(asr_gemm_desc d, int ktil
                                                                         __builtin_bit_cast(bf16x8, bh[j]), acc[i][j], 0, 0, 0);
                 }
         }
-        if (more) {
+        if (more && !(xcd_map & 4)) {
             __builtin_amdgcn_sched_barrier(0);   // keep the wait for the prefetched tile behind the MFMAs
             la.apply_mask(ra);
             lb.apply_mask(rb);
@@ -466,6 +478,364 @@ __global__ __launch_bounds__(256) void sgemm_bf_kernel(asr_gemm_desc d, int ktil
         __syncthreads();
         cur ^= 1;
     }
+    gemm_epilogue<TM, TN>(d, C, acc, m0, n0, wm, wn, WM, WN, split);
+}
+
+// ------------------------------------------------------------------ bf16, wide LDS reads --
+// Same arithmetic and tiling as sgemm_bf_kernel; the LDS images are laid out for the 256 B/clk read forms
+// (MI355X_MICROARCH.md, LDS: ds_read_b32 gets a quarter of that at one or two waves per SIMD, and the 32 of them per
+// k-step were 2/3 of the old kernel's time):
+//   mode 0 operand (k contiguous in memory): image [row][40 bf16] (32 k + 16 B of padding: a 16-lane group of a
+//     ds_read_b128 then covers all 16 bank quads); a lane's fragment of a 32x32x16 MFMA is ONE ds_read_b128;
+//     staged with ds_write_b64 (4 consecutive k of a row per float4).
+//   mode 1 operand (rows contiguous in memory): image [k][R + 32 bf16] (row pitch = 64 B mod 256 B: the 4 k rows of a
+//     transposed block sit on disjoint banks); staged with ds_write_b64 (4 consecutive rows at one k), fragment =
+//     two ds_read_b64_tr_b16 (4 k x 16 rows per 16-lane group, delivered k-major).
+typedef short s16x4g __attribute__((ext_vector_type(4)));
+typedef short s16x8g __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x2g __attribute__((ext_vector_type(2)));
+#define BF2_ROW0 80                                   // bytes per row of a mode-0 image
+#define BF2_PITCH1(R) (2 * (R) + 64)                  // bytes per k row of a mode-1 image
+#define BF2_IMG(R, MODE) ((MODE) == 0 ? (R) * BF2_ROW0 : BF_GK * BF2_PITCH1(R))
+
+template <int R, int MODE, int NPROD>
+__device__ __forceinline__ void store_tile_bf2(unsigned char *hi, unsigned char *lo, const float4 (&regs)[R * BF_GK / 1024]) {
+    const int tid = threadIdx.x;
+    constexpr int NS = R * BF_GK / 1024;
+#pragma unroll
+    for (int i = 0; i < NS; ++i) {
+        const int f = tid + 256 * i;
+        unsigned h0, l0, h1, l1;
+        bf_split(regs[i].x, regs[i].y, h0, l0);
+        bf_split(regs[i].z, regs[i].w, h1, l1);
+        const int off = MODE == 0 ? (f >> 3) * BF2_ROW0 + (f & 7) * 8 : (f / (R / 4)) * BF2_PITCH1(R) + (f % (R / 4)) * 8;
+        *reinterpret_cast<u32x2g *>(hi + off) = u32x2g{h0, h1};
+        if (NPROD > 1) *reinterpret_cast<u32x2g *>(lo + off) = u32x2g{l0, l1};
+    }
+}
+
+// fragment (row = r0 + lane&31, k = 16 ks + 8 (lane>>5) .. +7) of one image
+template <int R, int MODE>
+__device__ __forceinline__ bf16x8 frag_bf2(const unsigned char *img, int r0, int ks, int lane) {
+    if (MODE == 0) {
+        const u32x4g v = *reinterpret_cast<const u32x4g *>(img + (r0 + (lane & 31)) * BF2_ROW0 + (ks * 2 + (lane >> 5)) * 16);
+        return __builtin_bit_cast(bf16x8, v);
+    } else {
+        const int q = (lane & 15) >> 2, p = lane & 3;
+        const unsigned char *a = img + (16 * ks + 8 * (lane >> 5) + q) * BF2_PITCH1(R) + (r0 + 16 * ((lane >> 4) & 1) + 4 * p) * 2;
+        typedef __attribute__((address_space(3))) s16x4g *lds_p;
+        const s16x4g v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(a));
+        const s16x4g v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(a + 4 * BF2_PITCH1(R)));
+        const s16x8g v = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+        return __builtin_bit_cast(bf16x8, v);
+    }
+}
+
+template <int BM, int BN, int AMODE, int BMODE, int NPROD, bool KLIST = false>
+__global__ __launch_bounds__(256) void sgemm_bf2_kernel(asr_gemm_desc d, int ktiles_per_split, int flags) {
+    constexpr int GK = BF_GK;
+    constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
+    constexpr int LO = NPROD > 1 ? 2 : 1;
+    constexpr int IA = BF2_IMG(BM, AMODE), IB = BF2_IMG(BN, BMODE);
+    __shared__ __attribute__((aligned(16))) unsigned char Ah[2][IA];
+    __shared__ __attribute__((aligned(16))) unsigned char Bh[2][IB];
+    __shared__ __attribute__((aligned(16))) unsigned char Al[LO][NPROD > 1 ? IA : 16];
+    __shared__ __attribute__((aligned(16))) unsigned char Bl[LO][NPROD > 1 ? IB : 16];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    // Workgroups go to the 8 XCDs round-robin by linear id; XCD x works through one contiguous run of the tile order.
+    int bx = blockIdx.x, by = blockIdx.y;
+    if (flags & 1) {
+        const int nt = gridDim.x * gridDim.y, id = by * gridDim.x + bx;
+        const int q = nt >> 3, r = nt & 7, x = id & 7, loc = id >> 3;
+        const int tile = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + loc;
+        by = tile / gridDim.x;
+        bx = tile - by * gridDim.x;
+    }
+    const int n0 = bx * BN, m0 = by * BM;
+    const int batch = blockIdx.z / d.splitk, split = blockIdx.z % d.splitk;
+    const int bhi = d.batch_d > 0 ? batch / d.batch_d : 0, blo = batch - bhi * (d.batch_d > 0 ? d.batch_d : 0);
+    OperandView va{d.A + (int64_t)blo * d.batch_a + (int64_t)bhi * d.batch_a1, d.a_mode, d.a_s0, d.a_s1, d.a_d};
+    OperandView vb{d.B + (int64_t)blo * d.batch_b + (int64_t)bhi * d.batch_b1, d.b_mode, d.b_s0, d.b_s1, d.b_d};
+    float *C = d.C + (int64_t)blo * d.batch_c + (int64_t)bhi * d.batch_c1;
+
+    const int kbeg = split * ktiles_per_split * GK;
+    const int kend = min(d.K, kbeg + ktiles_per_split * GK);
+    const int nk = kend > kbeg ? (kend - kbeg + GK - 1) / GK : 0;
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    float4 ra[BM * GK / 1024], rb[BN * GK / 1024];
+    TileLoader<BM, GK, AMODE, true, KLIST, false> la;
+    TileLoader<BN, GK, BMODE, true, KLIST, false> lb;
+    const int32_t *kidx = d.k_idx;
+    const int klast = d.K - 1;
+    la.init(va, m0, d.M, AMODE == 0 ? d.m_idx : nullptr);
+    lb.init(vb, n0, d.N, nullptr);
+    if (nk > 0) {
+        la.init_klist(kidx, kbeg, klast);
+        lb.init_klist(kidx, kbeg, klast);
+        la.load(va, d.M, kbeg, kend, 1, ra, kidx, klast);
+        lb.load(vb, d.N, kbeg, kend, 1, rb, kidx, klast);
+        la.apply_mask(ra);
+        lb.apply_mask(rb);
+        store_tile_bf2<BM, AMODE, NPROD>(Ah[0], Al[0], ra);
+        store_tile_bf2<BN, BMODE, NPROD>(Bh[0], Bl[0], rb);
+    }
+    __syncthreads();
+
+    int cur = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+        const bool more = kt + 1 < nk;
+        if (more && !(flags & 2)) {
+            la.load(va, d.M, kbeg + (kt + 1) * GK, kend, 1, ra, kidx, klast);
+            lb.load(vb, d.N, kbeg + (kt + 1) * GK, kend, 1, rb, kidx, klast);
+        }
+        const int lcur = NPROD > 1 ? cur : 0;
+        if (!(flags & 8))
+#pragma unroll
+        for (int ks = 0; ks < GK / 16; ++ks) {
+            bf16x8 ah[TM], al[TM], bh[TN], bl[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                ah[i] = frag_bf2<BM, AMODE>(Ah[cur], wm * WM + i * 32, ks, lane);
+                if (NPROD > 1) al[i] = frag_bf2<BM, AMODE>(Al[lcur], wm * WM + i * 32, ks, lane);
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                bh[j] = frag_bf2<BN, BMODE>(Bh[cur], wn * WN + j * 32, ks, lane);
+                if (NPROD > 1) bl[j] = frag_bf2<BN, BMODE>(Bl[lcur], wn * WN + j * 32, ks, lane);
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    if (NPROD > 1) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+                    }
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+                }
+        }
+        if (more && !(flags & 4)) {
+            __builtin_amdgcn_sched_barrier(0);   // keep the wait for the prefetched tile behind the MFMAs
+            la.apply_mask(ra);
+            lb.apply_mask(rb);
+            store_tile_bf2<BM, AMODE, NPROD>(Ah[cur ^ 1], Al[NPROD > 1 ? cur ^ 1 : 0], ra);
+            store_tile_bf2<BN, BMODE, NPROD>(Bh[cur ^ 1], Bl[NPROD > 1 ? cur ^ 1 : 0], rb);
+        }
+        __syncthreads();
+        cur ^= 1;
+    }
+    if (!(flags & 16))
+    gemm_epilogue<TM, TN>(d, C, acc, m0, n0, wm, wn, WM, WN, split);
+}
+
+// ------------------------------------------------- bf16, software-pipelined main loop --
+// sgemm_bf2_kernel's images and arithmetic; the main loop keeps TWO k-tiles of global loads in flight and does the
+// split + LDS staging of tile kt+1 in the shadow of tile kt's MFMAs, in the SAME wave: after every (i, j) group of
+// MFMAs comes one slot's worth of split work (an MFMA holds the vector issue port for 8 of its 32 cycles; the rest is
+// free for independent instructions).  With the phases back to back instead (loads, MFMAs, wait, split, barrier) the
+// two workgroups of a CU fell into step and every phase ran alone: 27 % of the kernel's time had the matrix pipe busy.
+template <int N>
+struct IntTag { static constexpr int value = N; };
+
+template <int R, int MODE, int NPROD, bool MASK>
+__device__ __forceinline__ void store_slot_bf2(unsigned char *hi, unsigned char *lo, float4 v, unsigned okm, int i) {
+    const int f = threadIdx.x + 256 * i;
+    if (MASK) v = make_float4(__uint_as_float(__float_as_uint(v.x) & okm), __uint_as_float(__float_as_uint(v.y) & okm),
+                    __uint_as_float(__float_as_uint(v.z) & okm), __uint_as_float(__float_as_uint(v.w) & okm));
+    unsigned h0, l0, h1, l1;
+    bf_split(v.x, v.y, h0, l0);
+    bf_split(v.z, v.w, h1, l1);
+    const int off = MODE == 0 ? (f >> 3) * BF2_ROW0 + (f & 7) * 8 : (f / (R / 4)) * BF2_PITCH1(R) + (f % (R / 4)) * 8;
+    *reinterpret_cast<u32x2g *>(hi + off) = u32x2g{h0, h1};
+    if (NPROD > 1) *reinterpret_cast<u32x2g *>(lo + off) = u32x2g{l0, l1};
+}
+
+// Operand tile fetched with range-checked buffer loads: per slot ONE 32-bit byte offset fixed at set-up (row / column
+// part) plus a wave-uniform offset per k-tile; a slot outside the matrix gets an offset past the buffer and reads
+// zeros, so the main loop carries no pointer arithmetic, no selects and no masks.  Needs the operand's readable
+// span (asr_gemm_desc.a_span / b_span, < 2 GiB); mode 1 additionally a single-level k stride and no row list.
+#define BUF_OOB 0xfffffff0u
+template <int R, int GK, int MODE>
+struct BufLoader {
+    static constexpr int NS = R * GK / 1024;
+    __amdgpu_buffer_rsrc_t rsrc;
+    unsigned voff[NS];
+    int rk[NS];
+    int kstep;              // bytes per unit of k
+
+    __device__ __forceinline__ void init(const OperandView &v, int64_t span, int r0, int rmax, const int32_t *midx) {
+        const int tid = threadIdx.x;
+        rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(v.p), 0, (int)span, 0x00020000);
+        kstep = MODE == 0 ? 4 : (int)(v.s0 * 4);
+#pragma unroll
+        for (int i = 0; i < NS; ++i) {
+            const int f = tid + 256 * i;
+            if (MODE == 0) {
+                const int r = r0 + f / (GK / 4);
+                rk[i] = (f % (GK / 4)) * 4;
+                voff[i] = r < rmax ? (unsigned)((view_rowoff(v, midx ? midx[r] : r) + rk[i]) * 4) : BUF_OOB;
+            } else {
+                const int c = r0 + (f % (R / 4)) * 4;
+                rk[i] = f / (R / 4);
+                voff[i] = c < rmax ? (unsigned)(((int64_t)rk[i] * v.s0 + c) * 4) : BUF_OOB;
+            }
+        }
+    }
+    __device__ __forceinline__ void load(int k0, int kend, float4 (&regs)[NS]) const {
+        const int soff = k0 * kstep;
+        if (k0 + GK <= kend) {
+#pragma unroll
+            for (int i = 0; i < NS; ++i) {
+                const u32x4g v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)voff[i], soff, 0);
+                regs[i] = make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+            }
+        } else {            // the k-tile that holds kend: slots past it read zeros
+#pragma unroll
+            for (int i = 0; i < NS; ++i) {
+                const unsigned o = k0 + rk[i] < kend ? voff[i] : BUF_OOB;
+                const u32x4g v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)o, soff, 0);
+                regs[i] = make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+            }
+        }
+    }
+};
+
+template <int BM, int BN, int AMODE, int BMODE, int NPROD, bool KLIST = false, bool BUFA = false, bool BUFB = false>
+__global__ __launch_bounds__(256, 2) void sgemm_bf3_kernel(asr_gemm_desc d, int ktiles_per_split, int flags) {
+    constexpr int GK = BF_GK;
+    constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
+    constexpr int LO = NPROD > 1 ? 2 : 1;
+    constexpr int IA = BF2_IMG(BM, AMODE), IB = BF2_IMG(BN, BMODE);
+    constexpr int NSA = BM * GK / 1024, NSB = BN * GK / 1024, NSL = NSA + NSB;
+    constexpr int NCH = 2 * TM * TN;                       // MFMA groups per k-tile: (ks, i, j)
+    __shared__ __attribute__((aligned(16))) unsigned char Ah[2][IA];
+    __shared__ __attribute__((aligned(16))) unsigned char Bh[2][IB];
+    __shared__ __attribute__((aligned(16))) unsigned char Al[LO][NPROD > 1 ? IA : 16];
+    __shared__ __attribute__((aligned(16))) unsigned char Bl[LO][NPROD > 1 ? IB : 16];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    int bx = blockIdx.x, by = blockIdx.y;
+    if (flags & 1) {      // XCD x works through one contiguous run of the tile order (see sgemm_bf2_kernel)
+        const int nt = gridDim.x * gridDim.y, id = by * gridDim.x + bx;
+        const int q = nt >> 3, r = nt & 7, x = id & 7, loc = id >> 3;
+        const int tile = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + loc;
+        by = tile / gridDim.x;
+        bx = tile - by * gridDim.x;
+    }
+    const int n0 = bx * BN, m0 = by * BM;
+    const int batch = blockIdx.z / d.splitk, split = blockIdx.z % d.splitk;
+    const int bhi = d.batch_d > 0 ? batch / d.batch_d : 0, blo = batch - bhi * (d.batch_d > 0 ? d.batch_d : 0);
+    OperandView va{d.A + (int64_t)blo * d.batch_a + (int64_t)bhi * d.batch_a1, d.a_mode, d.a_s0, d.a_s1, d.a_d};
+    OperandView vb{d.B + (int64_t)blo * d.batch_b + (int64_t)bhi * d.batch_b1, d.b_mode, d.b_s0, d.b_s1, d.b_d};
+    float *C = d.C + (int64_t)blo * d.batch_c + (int64_t)bhi * d.batch_c1;
+
+    const int kbeg = split * ktiles_per_split * GK;
+    const int kend = min(d.K, kbeg + ktiles_per_split * GK);
+    const int nk = kend > kbeg ? (kend - kbeg + GK - 1) / GK : 0;
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    float4 ra[2][NSA], rb[2][NSB];
+    TileLoader<BM, GK, AMODE, true, KLIST, false> la;
+    TileLoader<BN, GK, BMODE, true, KLIST, false> lb;
+    BufLoader<BM, GK, AMODE> ba;
+    BufLoader<BN, GK, BMODE> bb;
+    const int32_t *kidx = d.k_idx;
+    const int klast = d.K - 1;
+    if (BUFA) ba.init(va, d.a_span - (va.p - d.A) * 4, m0, d.M, AMODE == 0 ? d.m_idx : nullptr);
+    else la.init(va, m0, d.M, AMODE == 0 ? d.m_idx : nullptr);
+    if (BUFB) bb.init(vb, d.b_span - (vb.p - d.B) * 4, n0, d.N, nullptr);
+    else lb.init(vb, n0, d.N, nullptr);
+    auto load_tile = [&](auto S, int kt) {     // k-tile kt -> register set S
+        constexpr int s = decltype(S)::value;
+        if (BUFA) ba.load(kbeg + kt * GK, kend, ra[s]);
+        else la.load(va, d.M, kbeg + kt * GK, kend, 1, ra[s], kidx, klast);
+        if (BUFB) bb.load(kbeg + kt * GK, kend, rb[s]);
+        else lb.load(vb, d.N, kbeg + kt * GK, kend, 1, rb[s], kidx, klast);
+    };
+    // slot sl of register set S (k-tile kt) -> LDS buffer buf; the in-range mask is recomputed here rather than kept
+    // in registers for two tiles in flight
+    auto stage_slot = [&](auto S, int buf, int sl, int kt) {
+        constexpr int s = decltype(S)::value;
+        const int lb_ = NPROD > 1 ? buf : 0;
+        const int k0 = kbeg + kt * GK;
+        if (sl < NSA) {
+            const unsigned ok = (BUFA || (la.base[sl] != nullptr && k0 + la.rk[sl] < kend)) ? 0xffffffffu : 0u;
+            store_slot_bf2<BM, AMODE, NPROD, !BUFA>(Ah[buf], Al[lb_], ra[s][sl], ok, sl);
+        } else {
+            const int t = sl - NSA;
+            const unsigned ok = (BUFB || (lb.base[t] != nullptr && k0 + lb.rk[t] < kend)) ? 0xffffffffu : 0u;
+            store_slot_bf2<BN, BMODE, NPROD, !BUFB>(Bh[buf], Bl[lb_], rb[s][t], ok, t);
+        }
+    };
+    if (nk > 0) {
+        if (!BUFA) la.init_klist(kidx, kbeg, klast);
+        if (!BUFB) lb.init_klist(kidx, kbeg, klast);
+        load_tile(IntTag<0>{}, 0);
+        if (nk > 1) load_tile(IntTag<1>{}, 1);
+#pragma unroll
+        for (int sl = 0; sl < NSL; ++sl) stage_slot(IntTag<0>{}, 0, sl, 0);
+    }
+    __syncthreads();
+
+    // one k-tile: LDS buffer P (= kt & 1) feeds the MFMAs, register set P^1 (tile kt+1) is staged into LDS buffer P^1,
+    // register set P (free since the previous iteration staged it) receives tile kt+2
+    auto body = [&](auto Ptag, int kt) {
+        constexpr int P = decltype(Ptag)::value;
+        const bool more = kt + 1 < nk;
+        if (kt + 2 < nk) load_tile(IntTag<P>{}, kt + 2);
+        constexpr int LP = NPROD > 1 ? P : 0;
+        bf16x8 ah[TM], al[TM], bh[TN], bl[TN];
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            const int ks = c / (TM * TN), i = (c % (TM * TN)) / TN, j = c % TN;
+            if (c % (TM * TN) == 0) {
+#pragma unroll
+                for (int ii = 0; ii < TM; ++ii) {
+                    ah[ii] = frag_bf2<BM, AMODE>(Ah[P], wm * WM + ii * 32, ks, lane);
+                    if (NPROD > 1) al[ii] = frag_bf2<BM, AMODE>(Al[LP], wm * WM + ii * 32, ks, lane);
+                }
+#pragma unroll
+                for (int jj = 0; jj < TN; ++jj) {
+                    bh[jj] = frag_bf2<BN, BMODE>(Bh[P], wn * WN + jj * 32, ks, lane);
+                    if (NPROD > 1) bl[jj] = frag_bf2<BN, BMODE>(Bl[LP], wn * WN + jj * 32, ks, lane);
+                }
+            }
+            if (NPROD > 1) {
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+            }
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+            if (more) {
+#pragma unroll
+                for (int sl = c * NSL / NCH; sl < (c + 1) * NSL / NCH; ++sl) stage_slot(IntTag<P ^ 1>{}, P ^ 1, sl, kt + 1);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        __syncthreads();
+    };
+    for (int kt = 0; kt < nk; kt += 2) {
+        body(IntTag<0>{}, kt);
+        if (kt + 1 < nk) body(IntTag<1>{}, kt + 1);
+    }
+    if (!(flags & 16))
     gemm_epilogue<TM, TN>(d, C, acc, m0, n0, wm, wn, WM, WN, split);
 }
 
@@ -556,23 +926,50 @@ extern "C" int asr_sgemm(const asr_gemm_desc *din, void *stream) {
         const int perb = cdiv(kt, sk);
         const int64_t zb = (int64_t)d.nbatch * sk;
         const int64_t t128 = (int64_t)cdiv(d.M, 128) * cdiv(d.N, 128) * zb, t12864 = (int64_t)cdiv(d.M, 128) * cdiv(d.N, 64) * zb;
-        static int bf_tile = -1;
+        static int bf_tile = -1, xcd_map = 1, bf_kernel = 3;
         if (bf_tile < 0) {
+            const char *k = getenv("ASR_GEMM_BF_KERNEL");
+            bf_kernel = k ? atoi(k) : 3;
             const char *e = getenv("ASR_GEMM_BF_TILE");
             bf_tile = e ? atoi(e) : 0;
+            const char *x = getenv("ASR_GEMM_XCD_MAP");
+            xcd_map = x ? atoi(x) : 1;
         }
+        if (getenv("ASR_GEMM_DEBUG_OCC")) {
+            static int once = 0;
+            if (!once) {
+                once = 1;
+                int n1 = -1, n2 = -1, n3 = -1;
+                hipOccupancyMaxActiveBlocksPerMultiprocessor(&n1, sgemm_bf_kernel<128, 128, 0, 0, 3, false>, 256, 0);
+                hipOccupancyMaxActiveBlocksPerMultiprocessor(&n2, sgemm_bf2_kernel<128, 128, 0, 0, 3, false>, 256, 0);
+                hipOccupancyMaxActiveBlocksPerMultiprocessor(&n3, sgemm_bf3_kernel<128, 128, 0, 0, 3, false>, 256, 0);
+                fprintf(stderr, "[asr_sgemm] workgroups per CU, 128x128 nt: bf %d, bf2 %d, bf3 %d\n", n1, n2, n3);
+            }
+        }
+        // buffer-load operand fetch: spans known and below 2 GiB, k offsets below 2 GiB, mode-1 operands single-level
+        const int64_t lim = 0x7ffffff0;
+        static int buf_env = -1;
+        if (buf_env < 0) { const char *e = getenv("ASR_GEMM_BUF"); buf_env = e ? atoi(e) : 1; }
+        const bool buf_a = buf_env && !d.k_idx && d.a_span > 0 && d.a_span <= lim &&
+                           (d.a_mode == 0 || (d.a_d == 0x7fffffff && (int64_t)d.K * d.a_s0 * 4 <= lim));
+        const bool buf_b = buf_env && !d.k_idx && d.b_span > 0 && d.b_span <= lim &&
+                           (d.b_mode == 0 || (d.b_d == 0x7fffffff && (int64_t)d.K * d.b_s0 * 4 <= lim));
         int shape = bf_tile ? bf_tile : (d.M >= 128 && d.N >= 128 && t128 >= 512 ? 1 : (d.M >= 128 && t12864 >= 384 ? 2 : 3));
-#define BF_LAUNCH(BM_, BN_, AM, BM2, NP, KL)                                                                    \
-    hipLaunchKernelGGL((sgemm_bf_kernel<BM_, BN_, AM, BM2, NP, KL>), grid, dim3(256), 0, st, d, perb)
+#define BF_LAUNCH(BM_, BN_, AM, BM2, NP, KL)                                                                           \
+    if (bf_kernel == 3 && buf_a && buf_b && !KL && NP == 3) hipLaunchKernelGGL((sgemm_bf3_kernel<BM_, BN_, AM, BM2, NP, false, true, true>), grid, dim3(256), 0, st, d, perb, xcd_map); \
+    else if (bf_kernel == 3 && buf_a && !KL && NP == 3) hipLaunchKernelGGL((sgemm_bf3_kernel<BM_, BN_, AM, BM2, NP, false, true, false>), grid, dim3(256), 0, st, d, perb, xcd_map); \
+    else if (bf_kernel == 3) hipLaunchKernelGGL((sgemm_bf3_kernel<BM_, BN_, AM, BM2, NP, KL>), grid, dim3(256), 0, st, d, perb, xcd_map); \
+    else if (bf_kernel == 2) hipLaunchKernelGGL((sgemm_bf2_kernel<BM_, BN_, AM, BM2, NP, KL>), grid, dim3(256), 0, st, d, perb, xcd_map); \
+    else hipLaunchKernelGGL((sgemm_bf_kernel<BM_, BN_, AM, BM2, NP, KL>), grid, dim3(256), 0, st, d, perb, xcd_map)
 #define BF_MODES(BM_, BN_, NP)                                   \
     switch (sel) {                                               \
-        case 0: BF_LAUNCH(BM_, BN_, 0, 0, NP, false); break;     \
-        case 1: BF_LAUNCH(BM_, BN_, 0, 1, NP, false); break;     \
-        case 2: BF_LAUNCH(BM_, BN_, 1, 0, NP, false); break;     \
-        default:                                                 \
-            if (d.k_idx) BF_LAUNCH(BM_, BN_, 1, 1, NP, true);    \
-            else BF_LAUNCH(BM_, BN_, 1, 1, NP, false);           \
-            break;                                               \
+        case 0: { BF_LAUNCH(BM_, BN_, 0, 0, NP, false); } break;     \
+        case 1: { BF_LAUNCH(BM_, BN_, 0, 1, NP, false); } break;     \
+        case 2: { BF_LAUNCH(BM_, BN_, 1, 0, NP, false); } break;     \
+        default:                                                     \
+            if (d.k_idx) { BF_LAUNCH(BM_, BN_, 1, 1, NP, true); }    \
+            else { BF_LAUNCH(BM_, BN_, 1, 1, NP, false); }           \
+            break;                                                   \
     }
 #define BF_SHAPE(BM_, BN_)                                                                          \
     {                                                                                               \

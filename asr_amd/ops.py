@@ -28,6 +28,24 @@ def _req(t, dtype=torch.float32):
     return t
 
 
+def _span(t, off, rows, inner, dd, s0, s1, nbatch, batch, batch_d, batch1, listed):
+    """Bytes readable from element `off` of tensor t if all the view's corners stay inside t, else 0."""
+    if not t.is_contiguous():
+        return 0
+    if listed:                      # rows named by a device list: any row of the tensor, single-level stride
+        return (t.numel() - off) * 4 if dd == 0 and nbatch == 1 else 0
+    r = rows - 1
+    row_c = (0, r * s0) if dd == 0 else (0, min(r, dd - 1) * s0, (r // dd) * s1, (r // dd) * s1 + (r % dd) * s0,
+                                         (r // dd) * s1 + (min(r, dd - 1)) * s0)
+    n = nbatch - 1
+    bat_c = (0,) if nbatch == 1 else ((0, n * batch) if batch_d == 0 else
+                                      (0, min(n, batch_d - 1) * batch, (n // batch_d) * batch1,
+                                       (n // batch_d) * batch1 + min(n, batch_d - 1) * batch))
+    lo = min(row_c) + min(bat_c)
+    hi = max(row_c) + max(bat_c) + inner
+    return (t.numel() - off) * 4 if lo >= 0 and off + hi <= t.numel() else 0
+
+
 def sgemm(A, B, Cm, M, N, K, *, a_mode=0, b_mode=0, a_stride=None, b_stride=None, c_stride=None,
           a_two=None, b_two=None, c_two=None, bias1=None, bias2=None, alpha=1.0, accumulate=False,
           act=0, splitk=1, nbatch=1, batch_a=0, batch_b=0, batch_c=0, a_off=0, b_off=0, c_off=0,
@@ -70,6 +88,13 @@ def sgemm(A, B, Cm, M, N, K, *, a_mode=0, b_mode=0, a_stride=None, b_stride=None
     # batch_two = (batch_d, a1, b1, c1): two-level batch index, see include/asr_amd.h
     d.batch_d, d.batch_a1, d.batch_b1, d.batch_c1 = (0, 0, 0, 0) if batch_two is None else batch_two
     d.pad_ok = pad_ok
+    # readable span of A and B from their pointers, when every element the views can name lies inside the tensor
+    # (a two-level view may step into ANOTHER allocation, e.g. the reverse direction's weights: then 0 = unknown)
+    bd, ba1, bb1 = (d.batch_d, d.batch_a1, d.batch_b1) if batch_two is not None else (0, 0, 0)
+    d.a_span = _span(A, a_off, M if a_mode == 0 else K, K if a_mode == 0 else M, d.a_d, d.a_s0, d.a_s1,
+                     nbatch, batch_a, bd, ba1, m_idx is not None or (k_idx is not None and a_mode == 1))
+    d.b_span = _span(B, b_off, N if b_mode == 0 else K, K if b_mode == 0 else N, d.b_d, d.b_s0, d.b_s1,
+                     nbatch, batch_b, bd, bb1, k_idx is not None and b_mode == 1)
     for name, idx, n in (("m_idx", m_idx, M), ("k_idx", k_idx, K)):
         if idx is None:
             setattr(d, name, 0)

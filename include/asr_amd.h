@@ -152,6 +152,10 @@ typedef struct {
      * 4 elements past M (resp. N) -- e.g. attention maps stored with a padded row stride -- so the
      * 16-byte loads may be used although M (N) is not a multiple of 4 */
     int pad_ok;
+    /* optional: bytes readable from A (resp. B), counted from the pointer in this descriptor (0 = unknown).  When both
+     * are given and below 2 GiB the bf16 kernels fetch the operands with range-checked buffer loads (no per-load
+     * address arithmetic or masks); results are identical either way. */
+    int64_t a_span, b_span;
 } asr_gemm_desc;
 
 int asr_sgemm(const asr_gemm_desc *d, void *stream);
