@@ -644,6 +644,69 @@ __global__ __launch_bounds__(256) void sgemm_bf2_kernel(asr_gemm_desc d, int kti
 // MFMAs comes one slot's worth of split work (an MFMA holds the vector issue port for 8 of its 32 cycles; the rest is
 // free for independent instructions).  With the phases back to back instead (loads, MFMAs, wait, split, barrier) the
 // two workgroups of a CU fell into step and every phase ran alone: 27 % of the kernel's time had the matrix pipe busy.
+// Epilogue with 16-byte stores: a 32x32 accumulator tile (lane = column, 4 consecutive rows per register quad) goes
+// through a wave-private 4 KB LDS image [row][32] (conflict-free both ways: ds_write_b32 by column, ds_read_b128 by
+// row quads) and leaves as float4 rows, 8 rows x 128 B per store instruction instead of 2 x 128 B, a quarter of the
+// store instructions and address arithmetic.  Needs split-K off, N % 4 == 0 and 16-byte aligned C rows (host-checked).
+template <int TM, int TN>
+__device__ __forceinline__ void gemm_epilogue_v4(const asr_gemm_desc &d, float *C, f32x16 (&acc)[TM][TN], int m0, int n0,
+                                                 int wm, int wn, int WM, int WN, float *scratch) {
+    const int lane = threadIdx.x & 63;
+    float *S = scratch + (threadIdx.x >> 6) * 1024;
+    OperandView vc{nullptr, 0, d.c_s0, d.c_s1, d.c_d};
+    const int rr = lane >> 3, c4 = (lane & 7) * 4;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        int64_t coff[4];
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const int row = m0 + wm * WM + i * 32 + p * 8 + rr;
+            coff[p] = row < d.M ? view_rowoff(vc, d.m_idx ? d.m_idx[row] : row) : -1;
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int col = n0 + wn * WN + j * 32 + c4;
+            float bias[4] = {0.f, 0.f, 0.f, 0.f};
+            if (col < d.N && (d.bias1 || d.bias2)) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int cc = col + e;
+                    const int bh = d.bias_d > 0 ? cc / d.bias_d : 0, bl = cc - bh * (d.bias_d > 0 ? d.bias_d : 0);
+                    if (d.bias1) bias[e] += d.bias1[bh * d.bias1_s1 + bl];
+                    if (d.bias2) bias[e] += d.bias2[bh * d.bias2_s1 + bl];
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the previous tile's row reads are done
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                S[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * 32 + (lane & 31)] = acc[i][j][r];
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                float4 v = *reinterpret_cast<const float4 *>(&S[(p * 8 + rr) * 32 + c4]);
+                if (coff[p] < 0 || col >= d.N) continue;
+                float *dst = C + coff[p] + col;
+                v = make_float4(d.alpha * v.x + bias[0], d.alpha * v.y + bias[1], d.alpha * v.z + bias[2], d.alpha * v.w + bias[3]);
+                if (d.accumulate) {
+                    const float4 o = *reinterpret_cast<const float4 *>(dst);
+                    v = make_float4(v.x + o.x, v.y + o.y, v.z + o.z, v.w + o.w);
+                }
+                if (d.act == 1) v = make_float4(tanh_f(v.x), tanh_f(v.y), tanh_f(v.z), tanh_f(v.w));
+                else if (d.act == 2) v = make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
+                if (d.c_keep) {
+                    const unsigned km = *reinterpret_cast<const unsigned *>(d.c_keep + (dst - d.C));
+                    const float ks = d.c_keep_scale;
+                    v = make_float4((km & 0xffu) ? v.x * ks : 0.f, (km & 0xff00u) ? v.y * ks : 0.f,
+                                    (km & 0xff0000u) ? v.z * ks : 0.f, (km & 0xff000000u) ? v.w * ks : 0.f);
+                }
+                *reinterpret_cast<float4 *>(dst) = v;
+            }
+        }
+    }
+}
+
 template <int N>
 struct IntTag { static constexpr int value = N; };
 
@@ -718,10 +781,14 @@ __global__ __launch_bounds__(256, 2) void sgemm_bf3_kernel(asr_gemm_desc d, int 
     constexpr int IA = BF2_IMG(BM, AMODE), IB = BF2_IMG(BN, BMODE);
     constexpr int NSA = BM * GK / 1024, NSB = BN * GK / 1024, NSL = NSA + NSB;
     constexpr int NCH = 2 * TM * TN;                       // MFMA groups per k-tile: (ks, i, j)
-    __shared__ __attribute__((aligned(16))) unsigned char Ah[2][IA];
-    __shared__ __attribute__((aligned(16))) unsigned char Bh[2][IB];
-    __shared__ __attribute__((aligned(16))) unsigned char Al[LO][NPROD > 1 ? IA : 16];
-    __shared__ __attribute__((aligned(16))) unsigned char Bl[LO][NPROD > 1 ? IB : 16];
+    // one pool: the operand images, reused by the epilogue's transposition image (4 KB per wave) after the main loop
+    constexpr int IAL = NPROD > 1 ? IA : 16, IBL = NPROD > 1 ? IB : 16;
+    constexpr int POOL0 = 2 * IA + 2 * IB + LO * IAL + LO * IBL, POOL = POOL0 > 16384 ? POOL0 : 16384;
+    __shared__ __attribute__((aligned(16))) unsigned char pool[POOL];
+    unsigned char(*Ah)[IA] = reinterpret_cast<unsigned char(*)[IA]>(pool);
+    unsigned char(*Bh)[IB] = reinterpret_cast<unsigned char(*)[IB]>(pool + 2 * IA);
+    unsigned char(*Al)[IAL] = reinterpret_cast<unsigned char(*)[IAL]>(pool + 2 * IA + 2 * IB);
+    unsigned char(*Bl)[IBL] = reinterpret_cast<unsigned char(*)[IBL]>(pool + 2 * IA + 2 * IB + LO * IAL);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
@@ -835,8 +902,9 @@ __global__ __launch_bounds__(256, 2) void sgemm_bf3_kernel(asr_gemm_desc d, int 
         body(IntTag<0>{}, kt);
         if (kt + 1 < nk) body(IntTag<1>{}, kt + 1);
     }
-    if (!(flags & 16))
-    gemm_epilogue<TM, TN>(d, C, acc, m0, n0, wm, wn, WM, WN, split);
+    if (flags & 16) return;
+    if (flags & 32) gemm_epilogue_v4<TM, TN>(d, C, acc, m0, n0, wm, wn, WM, WN, reinterpret_cast<float *>(pool));
+    else gemm_epilogue<TM, TN>(d, C, acc, m0, n0, wm, wn, WM, WN, split);
 }
 
 // 0: exact fp32 products (v_mfma_f32_32x32x2_f32); 1: bf16x3 split products; 2: plain bf16 products.
@@ -954,11 +1022,18 @@ extern "C" int asr_sgemm(const asr_gemm_desc *din, void *stream) {
                            (d.a_mode == 0 || (d.a_d == 0x7fffffff && (int64_t)d.K * d.a_s0 * 4 <= lim));
         const bool buf_b = buf_env && !d.k_idx && d.b_span > 0 && d.b_span <= lim &&
                            (d.b_mode == 0 || (d.b_d == 0x7fffffff && (int64_t)d.K * d.b_s0 * 4 <= lim));
+        // 16-byte epilogue stores: no split-K atomics, N % 4 == 0, C rows (and the keep mask) aligned
+        static int epi_env = -1;
+        if (epi_env < 0) { const char *e = getenv("ASR_GEMM_EPI4"); epi_env = e ? atoi(e) : 1; }
+        const bool vec_c = epi_env && sk == 1 && d.N % 4 == 0 && aligned16(d.C) && d.c_s0 % 4 == 0 &&
+                           (d.c_s1 % 4 == 0) && (d.nbatch == 1 || (d.batch_c % 4 == 0 && (!two || d.batch_c1 % 4 == 0))) &&
+                           (!d.c_keep || (((uintptr_t)d.c_keep) & 3) == 0);
+        const int kflags = (xcd_map & ~32) | (vec_c ? 32 : 0);
         int shape = bf_tile ? bf_tile : (d.M >= 128 && d.N >= 128 && t128 >= 512 ? 1 : (d.M >= 128 && t12864 >= 384 ? 2 : 3));
 #define BF_LAUNCH(BM_, BN_, AM, BM2, NP, KL)                                                                           \
-    if (bf_kernel == 3 && buf_a && buf_b && !KL && NP == 3) hipLaunchKernelGGL((sgemm_bf3_kernel<BM_, BN_, AM, BM2, NP, false, true, true>), grid, dim3(256), 0, st, d, perb, xcd_map); \
-    else if (bf_kernel == 3 && buf_a && !KL && NP == 3) hipLaunchKernelGGL((sgemm_bf3_kernel<BM_, BN_, AM, BM2, NP, false, true, false>), grid, dim3(256), 0, st, d, perb, xcd_map); \
-    else if (bf_kernel == 3) hipLaunchKernelGGL((sgemm_bf3_kernel<BM_, BN_, AM, BM2, NP, KL>), grid, dim3(256), 0, st, d, perb, xcd_map); \
+    if (bf_kernel == 3 && buf_a && buf_b && !KL && NP == 3) hipLaunchKernelGGL((sgemm_bf3_kernel<BM_, BN_, AM, BM2, NP, false, true, true>), grid, dim3(256), 0, st, d, perb, kflags); \
+    else if (bf_kernel == 3 && buf_a && !KL && NP == 3) hipLaunchKernelGGL((sgemm_bf3_kernel<BM_, BN_, AM, BM2, NP, false, true, false>), grid, dim3(256), 0, st, d, perb, kflags); \
+    else if (bf_kernel == 3) hipLaunchKernelGGL((sgemm_bf3_kernel<BM_, BN_, AM, BM2, NP, KL>), grid, dim3(256), 0, st, d, perb, kflags); \
     else if (bf_kernel == 2) hipLaunchKernelGGL((sgemm_bf2_kernel<BM_, BN_, AM, BM2, NP, KL>), grid, dim3(256), 0, st, d, perb, xcd_map); \
     else hipLaunchKernelGGL((sgemm_bf_kernel<BM_, BN_, AM, BM2, NP, KL>), grid, dim3(256), 0, st, d, perb, xcd_map)
 #define BF_MODES(BM_, BN_, NP)                                   \
