@@ -43,9 +43,7 @@ __device__ __forceinline__ int64_t view_rowoff(const OperandView &v, int i) {
 // Per-thread slots of a (R x GK) operand tile, R/64 float4s each.
 //   mode 0: element (r,k) at p[rowoff(r0+r) + k];   slot f -> r = f>>2, k4 = f&3   (row fixed per slot)
 //   mode 1: element (r,k) at p[rowoff(k) + r0+r];   slot f -> k = f/(R/4), r4 = f%(R/4)
-//   PAIRK (mode 1 only, the bf16 kernels): slots 2q and 2q+1 of a thread hold the SAME four rows at k = 2p and
-//   2p + 1, so the thread can pack the k pair of each row into one 32-bit word of two bf16.
-template <int R, int GK, int MODE, bool FAST, bool KLIST = false, bool PAIRK = false>
+template <int R, int GK, int MODE, bool FAST, bool KLIST = false>
 struct TileLoader {
     static constexpr int NS = R * GK / 1024;   // float4 slots per thread
     static constexpr int KQ = GK / 4;          // float4s per row (mode 0)
@@ -78,11 +76,6 @@ struct TileLoader {
                 base[i] = r < rmax ? v.p + view_rowoff(v, midx ? midx[r] : r) : nullptr;
                 rk[i] = (f % KQ) * 4;
                 rcol[i] = 0;
-            } else if (PAIRK) {
-                const int r = r0 + (tid % (R / 4)) * 4;
-                base[i] = r < rmax ? v.p + r : nullptr;
-                rk[i] = 2 * (tid / (R / 4) + (1024 / R) * (i >> 1)) + (i & 1);
-                rcol[i] = r;
             } else {
                 const int r = r0 + (f % (R / 4)) * 4;
                 base[i] = r < rmax ? v.p + r : nullptr;
@@ -313,14 +306,11 @@ __global__ __launch_bounds__(256) void sgemm_kernel(asr_gemm_desc d, int vecA, i
 // what is dropped -- a_lo b_lo and the residuals past 16 mantissa bits -- is below 2^-16 of |a||b| per
 // product; measured against the fp32 MFMA kernel in tests/test_gpu_parity.py::test_sgemm_bf16x3).  NPROD = 1 keeps
 // a_hi b_hi only: plain bf16 inputs (8 mantissa bits), an opt-in mode with a tolerance of its own.
-// LDS holds k-PAIR-major tiles of 32-bit words, word[kp][m] = {bf16 x[m][2kp], bf16 x[m][2kp+1]}: one
-// ds_read_b32 per lane and word is conflict-free (lanes = consecutive m), a lane's fragment of a
-// 32x32x16 MFMA (row m, k = 8h .. 8h+7) is words kp = 4h .. 4h+3.  GK = 32 (two k-steps per tile).
+// GK = 32 (two k-steps of 16 per tile).
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef unsigned int u32x4g __attribute__((ext_vector_type(4)));
 #define BF_GK 32
-#define BF_KP (BF_GK / 2)
 
 __device__ __forceinline__ unsigned bf_pack(float a, float b) {
     bf16x2 v = {(__bf16)a, (__bf16)b};      // v_cvt_pk_bf16_f32 (RNE; NaN stays NaN)
@@ -332,159 +322,8 @@ __device__ __forceinline__ void bf_split(float a, float b, unsigned &hi, unsigne
     lo = bf_pack(a - __uint_as_float(hi << 16), b - __uint_as_float(hi & 0xffff0000u));
 }
 
-template <int R, int MODE, int NPROD>
-__device__ __forceinline__ void store_tile_bf(unsigned (*hi)[R + GPAD(MODE)], unsigned (*lo)[R + GPAD(MODE)],
-                                              const float4 (&regs)[R * BF_GK / 1024]) {
-    const int tid = threadIdx.x;
-    constexpr int NS = R * BF_GK / 1024;
-    if (MODE == 0) {       // a slot = 4 consecutive k of one row: two words
-#pragma unroll
-        for (int i = 0; i < NS; ++i) {
-            const int f = tid + 256 * i;
-            const int r = f / (BF_GK / 4), kp = (f % (BF_GK / 4)) * 2;
-            unsigned h0, l0, h1, l1;
-            bf_split(regs[i].x, regs[i].y, h0, l0);
-            bf_split(regs[i].z, regs[i].w, h1, l1);
-            hi[kp][r] = h0;
-            hi[kp + 1][r] = h1;
-            if (NPROD > 1) {
-                lo[kp][r] = l0;
-                lo[kp + 1][r] = l1;
-            }
-        }
-    } else {               // PAIRK: slots 2q, 2q+1 = the same four rows at k = 2p, 2p+1: four words, one 16-byte store
-#pragma unroll
-        for (int q = 0; q < NS / 2; ++q) {
-            const int p = tid / (R / 4) + (1024 / R) * q, r = (tid % (R / 4)) * 4;
-            unsigned h0, h1, h2, h3, l0, l1, l2, l3;
-            bf_split(regs[2 * q].x, regs[2 * q + 1].x, h0, l0);
-            bf_split(regs[2 * q].y, regs[2 * q + 1].y, h1, l1);
-            bf_split(regs[2 * q].z, regs[2 * q + 1].z, h2, l2);
-            bf_split(regs[2 * q].w, regs[2 * q + 1].w, h3, l3);
-            *reinterpret_cast<u32x4g *>(&hi[p][r]) = u32x4g{h0, h1, h2, h3};
-            if (NPROD > 1) *reinterpret_cast<u32x4g *>(&lo[p][r]) = u32x4g{l0, l1, l2, l3};
-        }
-    }
-}
-
-template <int BM, int BN, int AMODE, int BMODE, int NPROD, bool KLIST = false>
-__global__ __launch_bounds__(256) void sgemm_bf_kernel(asr_gemm_desc d, int ktiles_per_split, int xcd_map) {
-    constexpr int GK = BF_GK;
-    constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
-    constexpr int LO = NPROD > 1 ? 2 : 1;     // the lo images only exist for the split
-    __shared__ __attribute__((aligned(16))) unsigned Ah[2][BF_KP][BM + GPAD(AMODE)];
-    __shared__ __attribute__((aligned(16))) unsigned Bh[2][BF_KP][BN + GPAD(BMODE)];
-    __shared__ __attribute__((aligned(16))) unsigned Al[LO][NPROD > 1 ? BF_KP : 1][BM + GPAD(AMODE)];
-    __shared__ __attribute__((aligned(16))) unsigned Bl[LO][NPROD > 1 ? BF_KP : 1][BN + GPAD(BMODE)];
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
-    // Workgroups are handed to the 8 XCDs round-robin by their linear id; each XCD has its own L2.  Renumber the
-    // tiles of a z-slice so that XCD x works through one contiguous run of the (row-major, N fastest) tile order:
-    // a row tile of A then lives in ONE L2 instead of being fetched by all eight.
-    int bx = blockIdx.x, by = blockIdx.y;
-    if (xcd_map & 1) {
-        const int nt = gridDim.x * gridDim.y, id = by * gridDim.x + bx;
-        const int q = nt >> 3, r = nt & 7, x = id & 7, loc = id >> 3;
-        const int tile = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + loc;
-        by = tile / gridDim.x;
-        bx = tile - by * gridDim.x;
-    }
-    const int n0 = bx * BN, m0 = by * BM;
-    const int batch = blockIdx.z / d.splitk, split = blockIdx.z % d.splitk;
-    const int bhi = d.batch_d > 0 ? batch / d.batch_d : 0, blo = batch - bhi * (d.batch_d > 0 ? d.batch_d : 0);
-    OperandView va{d.A + (int64_t)blo * d.batch_a + (int64_t)bhi * d.batch_a1, d.a_mode, d.a_s0, d.a_s1, d.a_d};
-    OperandView vb{d.B + (int64_t)blo * d.batch_b + (int64_t)bhi * d.batch_b1, d.b_mode, d.b_s0, d.b_s1, d.b_d};
-    float *C = d.C + (int64_t)blo * d.batch_c + (int64_t)bhi * d.batch_c1;
-
-    const int kbeg = split * ktiles_per_split * GK;
-    const int kend = min(d.K, kbeg + ktiles_per_split * GK);
-    const int nk = kend > kbeg ? (kend - kbeg + GK - 1) / GK : 0;
-
-    f32x16 acc[TM][TN];
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-    float4 ra[BM * GK / 1024], rb[BN * GK / 1024];
-    TileLoader<BM, GK, AMODE, true, KLIST, AMODE == 1> la;
-    TileLoader<BN, GK, BMODE, true, KLIST, BMODE == 1> lb;
-    const int32_t *kidx = d.k_idx;
-    const int klast = d.K - 1;
-    la.init(va, m0, d.M, AMODE == 0 ? d.m_idx : nullptr);
-    lb.init(vb, n0, d.N, nullptr);
-    if (nk > 0) {
-        la.init_klist(kidx, kbeg, klast);
-        lb.init_klist(kidx, kbeg, klast);
-        la.load(va, d.M, kbeg, kend, 1, ra, kidx, klast);
-        lb.load(vb, d.N, kbeg, kend, 1, rb, kidx, klast);
-        la.apply_mask(ra);
-        lb.apply_mask(rb);
-        store_tile_bf<BM, AMODE, NPROD>(Ah[0], Al[0], ra);
-        store_tile_bf<BN, BMODE, NPROD>(Bh[0], Bl[0], rb);
-    }
-    __syncthreads();
-
-    const int kh = lane >> 5, l31 = lane & 31;
-    int cur = 0;
-    for (int kt = 0; kt < nk; ++kt) {
-        const bool more = kt + 1 < nk;
-        if (more && !(xcd_map & 2)) {
-            la.load(va, d.M, kbeg + (kt + 1) * GK, kend, 1, ra, kidx, klast);
-            lb.load(vb, d.N, kbeg + (kt + 1) * GK, kend, 1, rb, kidx, klast);
-        }
-        const int lcur = NPROD > 1 ? cur : 0;
-        if (!(xcd_map & 8))
-#pragma unroll
-        for (int ks = 0; ks < GK / 16; ++ks) {
-            u32x4g ah[TM], al[TM], bh[TN], bl[TN];
-            const int kp = ks * 8 + kh * 4;
-#pragma unroll
-            for (int i = 0; i < TM; ++i) {
-                const int c = wm * WM + i * 32 + l31;
-                ah[i] = u32x4g{Ah[cur][kp][c], Ah[cur][kp + 1][c], Ah[cur][kp + 2][c], Ah[cur][kp + 3][c]};
-                if (NPROD > 1) al[i] = u32x4g{Al[lcur][kp][c], Al[lcur][kp + 1][c], Al[lcur][kp + 2][c], Al[lcur][kp + 3][c]};
-            }
-#pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                const int c = wn * WN + j * 32 + l31;
-                bh[j] = u32x4g{Bh[cur][kp][c], Bh[cur][kp + 1][c], Bh[cur][kp + 2][c], Bh[cur][kp + 3][c]};
-                if (NPROD > 1) bl[j] = u32x4g{Bl[lcur][kp][c], Bl[lcur][kp + 1][c], Bl[lcur][kp + 2][c], Bl[lcur][kp + 3][c]};
-            }
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j) {
-                    if (NPROD > 1) {
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, al[i]),
-                                                                            __builtin_bit_cast(bf16x8, bh[j]), acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ah[i]),
-                                                                            __builtin_bit_cast(bf16x8, bl[j]), acc[i][j], 0, 0, 0);
-                    }
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ah[i]),
-                                                                        __builtin_bit_cast(bf16x8, bh[j]), acc[i][j], 0, 0, 0);
-                }
-        }
-        if (more && !(xcd_map & 4)) {
-            __builtin_amdgcn_sched_barrier(0);   // keep the wait for the prefetched tile behind the MFMAs
-            la.apply_mask(ra);
-            lb.apply_mask(rb);
-            store_tile_bf<BM, AMODE, NPROD>(Ah[cur ^ 1], Al[NPROD > 1 ? cur ^ 1 : 0], ra);
-            store_tile_bf<BN, BMODE, NPROD>(Bh[cur ^ 1], Bl[NPROD > 1 ? cur ^ 1 : 0], rb);
-        }
-        __syncthreads();
-        cur ^= 1;
-    }
-    gemm_epilogue<TM, TN>(d, C, acc, m0, n0, wm, wn, WM, WN, split);
-}
-
-// ------------------------------------------------------------------ bf16, wide LDS reads --
-// Same arithmetic and tiling as sgemm_bf_kernel; the LDS images are laid out for the 256 B/clk read forms
-// (MI355X_MICROARCH.md, LDS: ds_read_b32 gets a quarter of that at one or two waves per SIMD, and the 32 of them per
-// k-step were 2/3 of the old kernel's time):
+// LDS images, laid out for the 256 B/clk read forms (MI355X_MICROARCH.md, LDS: ds_read_b32 gets a quarter of that at
+// one or two waves per SIMD; a first version that fetched every fragment with four of them spent 2/3 of its time there):
 //   mode 0 operand (k contiguous in memory): image [row][40 bf16] (32 k + 16 B of padding: a 16-lane group of a
 //     ds_read_b128 then covers all 16 bank quads); a lane's fragment of a 32x32x16 MFMA is ONE ds_read_b128;
 //     staged with ds_write_b64 (4 consecutive k of a row per float4).
@@ -497,22 +336,6 @@ typedef unsigned int u32x2g __attribute__((ext_vector_type(2)));
 #define BF2_ROW0 80                                   // bytes per row of a mode-0 image
 #define BF2_PITCH1(R) (2 * (R) + 64)                  // bytes per k row of a mode-1 image
 #define BF2_IMG(R, MODE) ((MODE) == 0 ? (R) * BF2_ROW0 : BF_GK * BF2_PITCH1(R))
-
-template <int R, int MODE, int NPROD>
-__device__ __forceinline__ void store_tile_bf2(unsigned char *hi, unsigned char *lo, const float4 (&regs)[R * BF_GK / 1024]) {
-    const int tid = threadIdx.x;
-    constexpr int NS = R * BF_GK / 1024;
-#pragma unroll
-    for (int i = 0; i < NS; ++i) {
-        const int f = tid + 256 * i;
-        unsigned h0, l0, h1, l1;
-        bf_split(regs[i].x, regs[i].y, h0, l0);
-        bf_split(regs[i].z, regs[i].w, h1, l1);
-        const int off = MODE == 0 ? (f >> 3) * BF2_ROW0 + (f & 7) * 8 : (f / (R / 4)) * BF2_PITCH1(R) + (f % (R / 4)) * 8;
-        *reinterpret_cast<u32x2g *>(hi + off) = u32x2g{h0, h1};
-        if (NPROD > 1) *reinterpret_cast<u32x2g *>(lo + off) = u32x2g{l0, l1};
-    }
-}
 
 // fragment (row = r0 + lane&31, k = 16 ks + 8 (lane>>5) .. +7) of one image
 template <int R, int MODE>
@@ -531,116 +354,8 @@ __device__ __forceinline__ bf16x8 frag_bf2(const unsigned char *img, int r0, int
     }
 }
 
-template <int BM, int BN, int AMODE, int BMODE, int NPROD, bool KLIST = false>
-__global__ __launch_bounds__(256) void sgemm_bf2_kernel(asr_gemm_desc d, int ktiles_per_split, int flags) {
-    constexpr int GK = BF_GK;
-    constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
-    constexpr int LO = NPROD > 1 ? 2 : 1;
-    constexpr int IA = BF2_IMG(BM, AMODE), IB = BF2_IMG(BN, BMODE);
-    __shared__ __attribute__((aligned(16))) unsigned char Ah[2][IA];
-    __shared__ __attribute__((aligned(16))) unsigned char Bh[2][IB];
-    __shared__ __attribute__((aligned(16))) unsigned char Al[LO][NPROD > 1 ? IA : 16];
-    __shared__ __attribute__((aligned(16))) unsigned char Bl[LO][NPROD > 1 ? IB : 16];
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
-    // Workgroups go to the 8 XCDs round-robin by linear id; XCD x works through one contiguous run of the tile order.
-    int bx = blockIdx.x, by = blockIdx.y;
-    if (flags & 1) {
-        const int nt = gridDim.x * gridDim.y, id = by * gridDim.x + bx;
-        const int q = nt >> 3, r = nt & 7, x = id & 7, loc = id >> 3;
-        const int tile = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + loc;
-        by = tile / gridDim.x;
-        bx = tile - by * gridDim.x;
-    }
-    const int n0 = bx * BN, m0 = by * BM;
-    const int batch = blockIdx.z / d.splitk, split = blockIdx.z % d.splitk;
-    const int bhi = d.batch_d > 0 ? batch / d.batch_d : 0, blo = batch - bhi * (d.batch_d > 0 ? d.batch_d : 0);
-    OperandView va{d.A + (int64_t)blo * d.batch_a + (int64_t)bhi * d.batch_a1, d.a_mode, d.a_s0, d.a_s1, d.a_d};
-    OperandView vb{d.B + (int64_t)blo * d.batch_b + (int64_t)bhi * d.batch_b1, d.b_mode, d.b_s0, d.b_s1, d.b_d};
-    float *C = d.C + (int64_t)blo * d.batch_c + (int64_t)bhi * d.batch_c1;
-
-    const int kbeg = split * ktiles_per_split * GK;
-    const int kend = min(d.K, kbeg + ktiles_per_split * GK);
-    const int nk = kend > kbeg ? (kend - kbeg + GK - 1) / GK : 0;
-
-    f32x16 acc[TM][TN];
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-    float4 ra[BM * GK / 1024], rb[BN * GK / 1024];
-    TileLoader<BM, GK, AMODE, true, KLIST, false> la;
-    TileLoader<BN, GK, BMODE, true, KLIST, false> lb;
-    const int32_t *kidx = d.k_idx;
-    const int klast = d.K - 1;
-    la.init(va, m0, d.M, AMODE == 0 ? d.m_idx : nullptr);
-    lb.init(vb, n0, d.N, nullptr);
-    if (nk > 0) {
-        la.init_klist(kidx, kbeg, klast);
-        lb.init_klist(kidx, kbeg, klast);
-        la.load(va, d.M, kbeg, kend, 1, ra, kidx, klast);
-        lb.load(vb, d.N, kbeg, kend, 1, rb, kidx, klast);
-        la.apply_mask(ra);
-        lb.apply_mask(rb);
-        store_tile_bf2<BM, AMODE, NPROD>(Ah[0], Al[0], ra);
-        store_tile_bf2<BN, BMODE, NPROD>(Bh[0], Bl[0], rb);
-    }
-    __syncthreads();
-
-    int cur = 0;
-    for (int kt = 0; kt < nk; ++kt) {
-        const bool more = kt + 1 < nk;
-        if (more && !(flags & 2)) {
-            la.load(va, d.M, kbeg + (kt + 1) * GK, kend, 1, ra, kidx, klast);
-            lb.load(vb, d.N, kbeg + (kt + 1) * GK, kend, 1, rb, kidx, klast);
-        }
-        const int lcur = NPROD > 1 ? cur : 0;
-        if (!(flags & 8))
-#pragma unroll
-        for (int ks = 0; ks < GK / 16; ++ks) {
-            bf16x8 ah[TM], al[TM], bh[TN], bl[TN];
-#pragma unroll
-            for (int i = 0; i < TM; ++i) {
-                ah[i] = frag_bf2<BM, AMODE>(Ah[cur], wm * WM + i * 32, ks, lane);
-                if (NPROD > 1) al[i] = frag_bf2<BM, AMODE>(Al[lcur], wm * WM + i * 32, ks, lane);
-            }
-#pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                bh[j] = frag_bf2<BN, BMODE>(Bh[cur], wn * WN + j * 32, ks, lane);
-                if (NPROD > 1) bl[j] = frag_bf2<BN, BMODE>(Bl[lcur], wn * WN + j * 32, ks, lane);
-            }
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j) {
-                    if (NPROD > 1) {
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
-                    }
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
-                }
-        }
-        if (more && !(flags & 4)) {
-            __builtin_amdgcn_sched_barrier(0);   // keep the wait for the prefetched tile behind the MFMAs
-            la.apply_mask(ra);
-            lb.apply_mask(rb);
-            store_tile_bf2<BM, AMODE, NPROD>(Ah[cur ^ 1], Al[NPROD > 1 ? cur ^ 1 : 0], ra);
-            store_tile_bf2<BN, BMODE, NPROD>(Bh[cur ^ 1], Bl[NPROD > 1 ? cur ^ 1 : 0], rb);
-        }
-        __syncthreads();
-        cur ^= 1;
-    }
-    if (!(flags & 16))
-    gemm_epilogue<TM, TN>(d, C, acc, m0, n0, wm, wn, WM, WN, split);
-}
-
-// ------------------------------------------------- bf16, software-pipelined main loop --
-// sgemm_bf2_kernel's images and arithmetic; the main loop keeps TWO k-tiles of global loads in flight and does the
-// split + LDS staging of tile kt+1 in the shadow of tile kt's MFMAs, in the SAME wave: after every (i, j) group of
+// ------------------------------------------------- software-pipelined main loop --
+// The main loop keeps TWO k-tiles of global loads in flight and does the split + LDS staging of tile kt+1 in the shadow of tile kt's MFMAs, in the SAME wave: after every (i, j) group of
 // MFMAs comes one slot's worth of split work (an MFMA holds the vector issue port for 8 of its 32 cycles; the rest is
 // free for independent instructions).  With the phases back to back instead (loads, MFMAs, wait, split, barrier) the
 // two workgroups of a CU fell into step and every phase ran alone: 27 % of the kernel's time had the matrix pipe busy.
@@ -793,7 +508,7 @@ __global__ __launch_bounds__(256, 2) void sgemm_bf3_kernel(asr_gemm_desc d, int 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     int bx = blockIdx.x, by = blockIdx.y;
-    if (flags & 1) {      // XCD x works through one contiguous run of the tile order (see sgemm_bf2_kernel)
+    if (flags & 1) {      // workgroups go to the 8 XCDs round-robin by linear id: XCD x works through one contiguous run of the tile order
         const int nt = gridDim.x * gridDim.y, id = by * gridDim.x + bx;
         const int q = nt >> 3, r = nt & 7, x = id & 7, loc = id >> 3;
         const int tile = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + loc;
@@ -820,8 +535,8 @@ __global__ __launch_bounds__(256, 2) void sgemm_bf3_kernel(asr_gemm_desc d, int 
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     float4 ra[2][NSA], rb[2][NSB];
-    TileLoader<BM, GK, AMODE, true, KLIST, false> la;
-    TileLoader<BN, GK, BMODE, true, KLIST, false> lb;
+    TileLoader<BM, GK, AMODE, true, KLIST> la;
+    TileLoader<BN, GK, BMODE, true, KLIST> lb;
     BufLoader<BM, GK, AMODE> ba;
     BufLoader<BN, GK, BMODE> bb;
     const int32_t *kidx = d.k_idx;
@@ -902,7 +617,6 @@ __global__ __launch_bounds__(256, 2) void sgemm_bf3_kernel(asr_gemm_desc d, int 
         body(IntTag<0>{}, kt);
         if (kt + 1 < nk) body(IntTag<1>{}, kt + 1);
     }
-    if (flags & 16) return;
     if (flags & 32) gemm_epilogue_v4<TM, TN>(d, C, acc, m0, n0, wm, wn, WM, WN, reinterpret_cast<float *>(pool));
     else gemm_epilogue<TM, TN>(d, C, acc, m0, n0, wm, wn, WM, WN, split);
 }
@@ -994,25 +708,12 @@ extern "C" int asr_sgemm(const asr_gemm_desc *din, void *stream) {
         const int perb = cdiv(kt, sk);
         const int64_t zb = (int64_t)d.nbatch * sk;
         const int64_t t128 = (int64_t)cdiv(d.M, 128) * cdiv(d.N, 128) * zb, t12864 = (int64_t)cdiv(d.M, 128) * cdiv(d.N, 64) * zb;
-        static int bf_tile = -1, xcd_map = 1, bf_kernel = 3;
+        static int bf_tile = -1, xcd_map = 1;
         if (bf_tile < 0) {
-            const char *k = getenv("ASR_GEMM_BF_KERNEL");
-            bf_kernel = k ? atoi(k) : 3;
             const char *e = getenv("ASR_GEMM_BF_TILE");
             bf_tile = e ? atoi(e) : 0;
             const char *x = getenv("ASR_GEMM_XCD_MAP");
-            xcd_map = x ? atoi(x) : 1;
-        }
-        if (getenv("ASR_GEMM_DEBUG_OCC")) {
-            static int once = 0;
-            if (!once) {
-                once = 1;
-                int n1 = -1, n2 = -1, n3 = -1;
-                hipOccupancyMaxActiveBlocksPerMultiprocessor(&n1, sgemm_bf_kernel<128, 128, 0, 0, 3, false>, 256, 0);
-                hipOccupancyMaxActiveBlocksPerMultiprocessor(&n2, sgemm_bf2_kernel<128, 128, 0, 0, 3, false>, 256, 0);
-                hipOccupancyMaxActiveBlocksPerMultiprocessor(&n3, sgemm_bf3_kernel<128, 128, 0, 0, 3, false>, 256, 0);
-                fprintf(stderr, "[asr_sgemm] workgroups per CU, 128x128 nt: bf %d, bf2 %d, bf3 %d\n", n1, n2, n3);
-            }
+            xcd_map = x ? (atoi(x) & 1) : 1;
         }
         // buffer-load operand fetch: spans known and below 2 GiB, k offsets below 2 GiB, mode-1 operands single-level
         const int64_t lim = 0x7ffffff0;
@@ -1028,14 +729,14 @@ extern "C" int asr_sgemm(const asr_gemm_desc *din, void *stream) {
         const bool vec_c = epi_env && sk == 1 && d.N % 4 == 0 && aligned16(d.C) && d.c_s0 % 4 == 0 &&
                            (d.c_s1 % 4 == 0) && (d.nbatch == 1 || (d.batch_c % 4 == 0 && (!two || d.batch_c1 % 4 == 0))) &&
                            (!d.c_keep || (((uintptr_t)d.c_keep) & 3) == 0);
-        const int kflags = (xcd_map & ~32) | (vec_c ? 32 : 0);
+        const int kflags = xcd_map | (vec_c ? 32 : 0);
         int shape = bf_tile ? bf_tile : (d.M >= 128 && d.N >= 128 && t128 >= 512 ? 1 : (d.M >= 128 && t12864 >= 384 ? 2 : 3));
-#define BF_LAUNCH(BM_, BN_, AM, BM2, NP, KL)                                                                           \
-    if (bf_kernel == 3 && buf_a && buf_b && !KL && NP == 3) hipLaunchKernelGGL((sgemm_bf3_kernel<BM_, BN_, AM, BM2, NP, false, true, true>), grid, dim3(256), 0, st, d, perb, kflags); \
-    else if (bf_kernel == 3 && buf_a && !KL && NP == 3) hipLaunchKernelGGL((sgemm_bf3_kernel<BM_, BN_, AM, BM2, NP, false, true, false>), grid, dim3(256), 0, st, d, perb, kflags); \
-    else if (bf_kernel == 3) hipLaunchKernelGGL((sgemm_bf3_kernel<BM_, BN_, AM, BM2, NP, KL>), grid, dim3(256), 0, st, d, perb, kflags); \
-    else if (bf_kernel == 2) hipLaunchKernelGGL((sgemm_bf2_kernel<BM_, BN_, AM, BM2, NP, KL>), grid, dim3(256), 0, st, d, perb, xcd_map); \
-    else hipLaunchKernelGGL((sgemm_bf_kernel<BM_, BN_, AM, BM2, NP, KL>), grid, dim3(256), 0, st, d, perb, xcd_map)
+#define BF_LAUNCH(BM_, BN_, AM, BM2, NP, KL)                                                                          \
+    if (buf_a && buf_b && !KL && NP == 3)                                                                             \
+        hipLaunchKernelGGL((sgemm_bf3_kernel<BM_, BN_, AM, BM2, NP, false, true, true>), grid, dim3(256), 0, st, d, perb, kflags); \
+    else if (buf_a && !KL && NP == 3)                                                                                 \
+        hipLaunchKernelGGL((sgemm_bf3_kernel<BM_, BN_, AM, BM2, NP, false, true, false>), grid, dim3(256), 0, st, d, perb, kflags); \
+    else hipLaunchKernelGGL((sgemm_bf3_kernel<BM_, BN_, AM, BM2, NP, KL>), grid, dim3(256), 0, st, d, perb, kflags)
 #define BF_MODES(BM_, BN_, NP)                                   \
     switch (sel) {                                               \
         case 0: { BF_LAUNCH(BM_, BN_, 0, 0, NP, false); } break;     \
@@ -1058,7 +759,7 @@ extern "C" int asr_sgemm(const asr_gemm_desc *din, void *stream) {
 #undef BF_SHAPE
 #undef BF_MODES
 #undef BF_LAUNCH
-        ASR_CHECK_LAUNCH("sgemm_bf_kernel");
+        ASR_CHECK_LAUNCH("sgemm_bf3_kernel");
         return ASR_OK;
     }
 #define LAUNCH(BM_, BN_, GK_, AM, BM2, F)                                                              \
