@@ -133,8 +133,14 @@ def elem_delta(a, b):
 
 
 def pick_splitk(M, N, K, nbatch=1):
-    """Split K over workgroups until the launch has about three 128x128 tiles per CU
-    (weight gradients: small M x N, K = all frames of the batch)."""
+    """Split K over workgroups (weight gradients: small M x N, K = all frames of the batch).  With 8 or more 128x128
+    tiles: as many splits as keep the launch within ONE resident round of 512 workgroups (2 per CU) -- a second,
+    partly filled round costs more than the longer K loops, and every split adds an M x N pass of float atomics
+    (tools/gemm_splitk.py).  Fewer tiles: 64x64 tiles, about three workgroups per CU."""
+    if M >= 128 and N >= 128:
+        c128 = ((M + 127) // 128) * ((N + 127) // 128) * nbatch
+        if c128 >= 8:
+            return int(max(1, min(512 // c128, K // 512, 64)))
     if M < 128 or N < 128:
         tiles = ((M + 63) // 64) * ((N + 63) // 64) * nbatch
     else:
