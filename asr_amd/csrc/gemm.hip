@@ -730,9 +730,10 @@ extern "C" int asr_sgemm(const asr_gemm_desc *din, void *stream) {
                            (d.c_s1 % 4 == 0) && (d.nbatch == 1 || (d.batch_c % 4 == 0 && (!two || d.batch_c1 % 4 == 0))) &&
                            (!d.c_keep || (((uintptr_t)d.c_keep) & 3) == 0);
         const int kflags = xcd_map | (vec_c ? 32 : 0);
-        // split-K launches sized for one resident round (asr_amd/ops.py pick_splitk) keep the 128 x 128 tile
+        // 128 x 128 tiles from 320 of them on (measured down to 375: tools/gemm_tile_pick.py; at 188 the 64 x 64 tile wins);
+        // split-K launches sized for one resident round (asr_amd/ops.py pick_splitk) keep them from 256 on
         int shape = bf_tile ? bf_tile
-                            : (d.M >= 128 && d.N >= 128 && (t128 >= 512 || (sk > 1 && t128 >= 256)) ? 1
+                            : (d.M >= 128 && d.N >= 128 && (t128 >= 320 || (sk > 1 && t128 >= 256)) ? 1
                                                                                                    : (d.M >= 128 && t12864 >= 384 ? 2 : 3));
 #define BF_LAUNCH(BM_, BN_, AM, BM2, NP, KL)                                                                          \
     if (buf_a && buf_b && !KL && NP == 3)                                                                             \

@@ -222,7 +222,7 @@ def roofline_probe(hp, dev, in_step=None):
     # products counted; `fp32_equivalent_tflops` is 2 M N K / time
     out["sgemm_proj"] = {"bound": "mfma", "achieved": 3.0 * flops / dt / 1e12, "peak": MFMA_BF16_PEAK_TFLOPS,
                          "unit": "TFLOP/s", "frac": 3.0 * flops / dt / 1e12 / MFMA_BF16_PEAK_TFLOPS, "traffic": None,
-                         "kernel": "sgemm_bf_kernel<128,128,0,0,3> (bf16x3 split)", "shape": [M, N, K],
+                         "kernel": "sgemm_bf3_kernel<128,128,0,0,3> (bf16x3 split, buffer loads)", "shape": [M, N, K],
                          "avg_us": dt * 1e6, "fp32_equivalent_tflops": flops / dt / 1e12,
                          "fp32_equivalent_frac_of_fp32_mfma_peak": flops / dt / 1e12 / MFMA_F32_PEAK_TFLOPS}
     # (3) fused label-smoothed CE: logits read once + gradient written once
