@@ -729,7 +729,8 @@ static bool al16(const void *p) { return (((uintptr_t)p) & 15) == 0; }
 //   * the column chunk k of hbatch[b] (all frames): 20 float4 per lane for the context sum,
 // so a step's energies and context cost no memory traffic at all (the per-step kernels stream 2 x 41 MB per step).
 // The M = 32 products of a step are 16 x 16 tile jobs on the same workgroups: cell jobs (4 hidden units x 16 batch
-// rows) on workgroups [0, NJ*MTB), state-projection jobs (16 attention units x 16 rows) on the next NSP*MTB.
+// rows) on workgroups [0, NJ*MTB), state-projection jobs (16 attention units x 16 rows) on the next NSP*MTB -- or, where
+// the grid ends first (short utterances), the remaining ones on the first cell workgroups as a second job.
 // Per label step the data crosses workgroups four times:
 //   sproj_s[b]     -> energy (b, k)                           (edge P, 2.5 KB in per workgroup)
 //   e[b, 64 frames]-> softmax + context chunk, all (b, *)     (edge E, 2 KB in)
@@ -911,11 +912,14 @@ __global__ __launch_bounds__(PD_THREADS) void attdec_fwd_persist_kernel(PDParams
                                   __uint_as_float(__float_as_uint(v.z) & mk), __uint_as_float(__float_as_uint(v.w) & mk));
         }
     }
-    // ---- job role: one 16 x 16 tile job per workgroup at most (the host checks)
+    // ---- job roles: cell jobs on workgroups [0, ncell); state projection jobs on the workgroups behind them, and,
+    // when those run out (ncell + nsp > workgroups: short utterances), one each on the first cell workgroups as well
     const int ncell = p.NJ * MTB, nsp = p.NSP * MTB;
-    const bool is_cell = w < ncell, is_sp = !is_cell && w < ncell + nsp;
-    const int jw = is_cell ? w : w - ncell;
-    const int jt = jw / MTB, jb0 = 16 * (jw - jt * MTB);     // tile index along units / attention units, first batch row
+    const int nsp_own = min(nsp, (int)gridDim.x - ncell);     // state projection jobs with a workgroup of their own
+    const bool is_cell = w < ncell;
+    const int sp_job = !is_cell ? (w - ncell < nsp_own ? w - ncell : -1) : (nsp_own + w < nsp ? nsp_own + w : -1);
+    const int jw = is_cell ? w : 0;
+    const int jt = jw / MTB, jb0 = 16 * (jw - jt * MTB);     // cell job: tile index along the units, first batch row
     int kqE = (E + 31) / 32, kqH = (Hd + 31) / 32;
     kqE = (kqE + 3) & ~3;
     kqH = (kqH + 3) & ~3;
@@ -1193,15 +1197,17 @@ __global__ __launch_bounds__(PD_THREADS) void attdec_fwd_persist_kernel(PDParams
 #endif
         // ---- E. products with S_{s+1}: state projection of the next step; W_ss S_{s+1} of the next cell job
 #ifndef PD_NO_E
-        if ((is_cell || is_sp) && s + 1 < L) {
+        // one 16 x 16 product with S_{s+1}: cellmode -> W_ss rows of cell job (ejt, ejb0) into accS; otherwise the state
+        // projection job (ejt, ejb0), published for the next step's phase A
+        auto do_E = [&](bool cellmode, int ejt, int ejb0) {
             const int tid = pd_opaque((int)threadIdx.x);
             const int lane = tid & 63, wave = tid >> 6, q = lane >> 4, ji = lane & 15;
-            const int jrow = jb0 + ji;
-            const int cu = 4 * jt + (ji & 3);
+            const int jrow = ejb0 + ji;
+            const int cu = 4 * ejt + (ji & 3);
             const int kbH = (wave * 4 + q) * kqH, keH = min(Hd, kbH + kqH);
-            // weight row of this lane: cell job -> gate (ji >> 2) of unit cu; state projection -> attention unit 16 jt + ji
-            const float *wrow_S = is_cell ? (cu < Hd ? a.W_ss + ((int64_t)(ji >> 2) * Hd + cu) * Hd : nullptr)
-                                          : (16 * jt + ji < A ? a.W_se + (int64_t)(16 * jt + ji) * Hd : nullptr);
+            // weight row of this lane: cell job -> gate (ji >> 2) of unit cu; state projection -> attention unit 16 ejt + ji
+            const float *wrow_S = cellmode ? (cu < Hd ? a.W_ss + ((int64_t)(ji >> 2) * Hd + cu) * Hd : nullptr)
+                                           : (16 * ejt + ji < A ? a.W_se + (int64_t)(16 * ejt + ji) * Hd : nullptr);
             constexpr int KFH = 3;         // Hd <= 32 slots x 12
             float4 wv[KFH];
 #pragma unroll
@@ -1213,7 +1219,6 @@ __global__ __launch_bounds__(PD_THREADS) void attdec_fwd_persist_kernel(PDParams
             float4 av[KFH];
             // probe: lanes 0..2 of each k-slot look at one granule of each of the slot's producers
             pd_gather<KFH>(av, rX, off, ep, ji == 0 ? off[0] : (ji == 1 ? off[1] : (ji == 2 ? off[2] : PD_OOB)), s_abort, p.err);
-            PD_STAMP(7);
             Tile16Acc acc;
             tile16_init(acc);
 #pragma unroll
@@ -1225,17 +1230,30 @@ __global__ __launch_bounds__(PD_THREADS) void attdec_fwd_persist_kernel(PDParams
             }
             tile16_reduce(acc, red16e);
             if (*s_abort) return;
-            if (is_cell) {
+            if (cellmode) {
                 if (tid < 256) accS[(tid >> 4) * 17 + (tid & 15)] = tile16_get(red16e, tid >> 4, tid & 15);
             } else if (tid < 64) {
                 const int bi = tid >> 2, n4 = (tid & 3) * 4;
-                const int bb = jb0 + bi, n0 = 16 * jt + n4;
+                const int bb = ejb0 + bi, n0 = 16 * ejt + n4;
                 if (bb < B && n0 < A) {
                     const float4 v = make_float4(tile16_get(red16e, bi, n4), tile16_get(red16e, bi, n4 + 1),
                                                  tile16_get(red16e, bi, n4 + 2), tile16_get(red16e, bi, n4 + 3));
                     pd_st4_tag(rX, ((slot * B + bb) * A16 + n0) * 4, v, ep);
                     *reinterpret_cast<float4 *>(a.sproj + (int64_t)(s + 1) * BA + (int64_t)bb * A + n0) = v;
                 }
+            }
+        };
+        if (s + 1 < L) {
+            // a state projection job first (the next step's phase A waits for it), then the cell job's own W_ss term
+            if (sp_job >= 0) {
+                do_E(false, sp_job / MTB, 16 * (sp_job % MTB));
+                if (*s_abort) return;
+                PD_STAMP(7);
+                if (is_cell) __syncthreads();        // red16e is read by the first 64 threads above
+            }
+            if (is_cell) {
+                do_E(true, jt, jb0);
+                if (*s_abort) return;
             }
             PD_STAMP(8);
         }
@@ -1362,7 +1380,7 @@ static int run_attdec_fwd(const asr_attdec_fwd_args *a, const GreedyParams *gp, 
         const int64_t xfl = attdec_ws_xch_floats(B, T, E, Hd);
         const int64_t nwg = (int64_t)B * NTILE;
         if (attdec_persist_on() && !gp && use_v2 && vecH && vecS && vecG && A % 16 == 0 && nwg <= n_cu &&
-            (int64_t)(p.NJ + p.NSP) * MTB <= nwg && A16p <= 32 * PD_MTP && E <= 128 * PD_KF && Hd <= 384 &&
+            (int64_t)p.NJ * MTB <= nwg && (int64_t)p.NSP * MTB <= nwg && A16p <= 32 * PD_MTP && E <= 128 * PD_KF && Hd <= 384 &&
             p.EC / 4 <= PD_THREADS && (int64_t)p.nfg * PD_HF >= T && psm <= 150 * 1024 && xfl * 4 < (int64_t)0x7fff0000 &&
             al16(a->g) && al16(a->sproj) && al16(a->ws)) {
             static thread_local bool attr3 = false;

@@ -447,7 +447,8 @@ int64_t asr_attdec_ws_floats(int B, int T, int E, int Hd, int L);
 int asr_attdec_fwd(const asr_attdec_fwd_args *a, void *stream);
 /* asr_attdec_fwd runs the whole loop as ONE persistent launch when the (B x ceil(T/64)) workgroups each get a
  * compute unit and the shape fits its register-resident layout (2*Hd <= 640, E <= 640, Hd <= 384, the
- * cell / state-projection tile jobs <= workgroups; csrc/attdec.hip), else four launches per label step.
+ * cell tile jobs and the state-projection tile jobs each <= workgroups; csrc/attdec.hip), else four launches per
+ * label step.
  * asr_attdec_persist(0 / 1) switches the one-launch form off / on (returns the previous setting; any other
  * value only queries); environment variable ASR_ATTDEC_PERSIST=1 / 0 sets it for the process (default: on).
  * asr_attdec_err_offset: index (in floats) inside a->ws of a 4-byte word that is non-zero after the call iff an
