@@ -258,12 +258,21 @@ __global__ __launch_bounds__(256) void blstm_fwd_persist_kernel(
     const float *__restrict__ W_hh, float *__restrict__ G, float *__restrict__ Cs,
     float *__restrict__ Hout, int64_t ho_t, int64_t ho_b, int64_t hout_bytes,
     const int32_t *__restrict__ lengths, int T, int B, int H, int s0, int s1, float *hx, unsigned *flags,
-    unsigned *err, int dbg, int tagmode) {
-    static_assert(MT * NT == 2 || (MT == 1 && NT == 1), "128 (64) owner threads");
+    unsigned *err, int dbg, int tagmode, int xcd_nbt = 0, unsigned xcd_epoch = 0) {
+    static_assert(MT * NT == 2 || (MT == 1 && NT == 1) || (MT == 1 && NT == 4), "64, 128 or 256 owner threads");
     constexpr int UN = 4 * NT;                               // hidden units per workgroup
     __shared__ float red[2][4][MT][NT][16][17];
-    __shared__ int s_abort;
-    const int jt = blockIdx.x, d = blockIdx.y, bt = blockIdx.z, NJ = gridDim.x, NBT = gridDim.z;
+    __shared__ int s_abort, s_local;
+    // Classic grid: (NJ, 2, NBT).  XCD-grouped grid (xcd_nbt > 0): 8 * NJ workgroups in one dimension; workgroups are
+    // dealt round-robin over the 8 XCDs, so id & 7 labels the XCD and each (direction, batch tile) group takes the
+    // workgroups of ONE label (labels 2 * xcd_nbt .. 7 leave at once).  Whether the group really shares an XCD is
+    // checked below from HW_REG_XCC_ID before anything relies on it.
+    int jt = blockIdx.x, d = blockIdx.y, bt = blockIdx.z, NJ = gridDim.x, NBT = gridDim.z;
+    if (xcd_nbt > 0) {
+        const int grp = blockIdx.x & 7;
+        if (grp >= 2 * xcd_nbt) return;
+        jt = blockIdx.x >> 3; d = grp & 1; bt = grp >> 1; NJ = gridDim.x >> 3; NBT = xcd_nbt;
+    }
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i = lane & 15, q = lane >> 4;
     constexpr int KQ = KQ4 * 4;
@@ -308,8 +317,35 @@ __global__ __launch_bounds__(256) void blstm_fwd_persist_kernel(
     float *hxd = hx + (int64_t)(d * NBT + bt) * 2 * NJ * chunk;
     __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(hxd, 0, 2 * NJ * chunk * 4, 0x00020000);
     unsigned *fl = flags + (d * NBT + bt) * NJ;
-    if (tid == 0) s_abort = 0;
+    if (tid == 0) { s_abort = 0; s_local = 0; }
     __syncthreads();
+    // XCD-grouped grid: every workgroup publishes the XCD it runs on (sc1 store, stamped with this launch's epoch);
+    // if all NJ members of the group report the same XCD, the h exchange uses PLAIN stores -- the line stays in that
+    // XCD's L2, where the consumers' sc1 loads (L1 bypass, L2-served) find it without the trip through the fabric.
+    // Any other outcome (mixed placement, a member that does not show up within the bounded poll) keeps the
+    // write-through stores: the choice only changes latency, every member of a group reads the same words and so
+    // makes the same choice.
+    if (xcd_nbt > 0) {
+        unsigned xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        xcc &= 0xffu;
+        unsigned *xid = flags + 512 + (d * NBT + bt) * 64;
+        if (tid == 0) __hip_atomic_store(xid + jt, (xcd_epoch << 8) | xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (wave == 0) {
+            unsigned v = 0;
+            bool ok = false;
+            for (int spins = 0; spins < (1 << 16); ++spins) {
+                v = lane < NJ ? __hip_atomic_load(xid + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : ((xcd_epoch << 8) | xcc);
+                ok = (v >> 8) == xcd_epoch;
+                if (__all(ok)) break;
+                __builtin_amdgcn_s_sleep(1);
+            }
+            const bool same = __all(ok && (v & 0xffu) == xcc);
+            if (lane == 0) s_local = same && !(dbg & 16);
+        }
+        __syncthreads();
+    }
+    const bool xlocal = s_local != 0;
 
     // Order of the vector-memory instructions inside a step (s_waitcnt vmcnt counts loads AND
     // stores, in issue order, so whatever is issued before the exchange loads is waited for with
@@ -382,7 +418,8 @@ __global__ __launch_bounds__(256) void blstm_fwd_persist_kernel(
                     const unsigned e = (unsigned)((s >> 1) & 1);
                     pk = u32x4{tag_bits(h, e), tag_bits(h1, e), tag_bits(h2, e), tag_bits(h3, e)};
                 }
-                __builtin_amdgcn_raw_buffer_store_b128(pk, rsrc, (((s & 1) * NJ + jt) * chunk + bl * UN + u) * 4, 0, 16);
+                if (xlocal) __builtin_amdgcn_raw_buffer_store_b128(pk, rsrc, (((s & 1) * NJ + jt) * chunk + bl * UN + u) * 4, 0, 0);
+                else __builtin_amdgcn_raw_buffer_store_b128(pk, rsrc, (((s & 1) * NJ + jt) * chunk + bl * UN + u) * 4, 0, 16);
             }
             sv[0] = ig; sv[1] = fg; sv[2] = gg; sv[3] = og; sv[4] = cn; sv[5] = h;
             sv_g = growb;
@@ -673,15 +710,21 @@ __global__ __launch_bounds__(256) void blstm_bwd_rs_kernel(
     const float *__restrict__ W_hh, float *__restrict__ G, const float *__restrict__ Cs,
     const float *__restrict__ dHout, int64_t dho_t, int64_t dho_b, const int32_t *__restrict__ lengths,
     int64_t dh_bytes, int T, int B, int H, int s0, int s1, float *__restrict__ dc_ws, float *xP, unsigned *flags,
-    unsigned *err, int dbg, int tagmode) {
+    unsigned *err, int dbg, int tagmode, int xcd_nbt = 0, unsigned xcd_epoch = 0) {
     constexpr int KL = 4 * UW, KS = KL / 4, DSTR = KL + 4;
     constexpr int NI = 16 * UW / 4;     // 16-byte items per source workgroup (16 rows x UW/4)
     constexpr int NG = 256 / NI;        // thread groups that split the sources
     constexpr int KSB = KL / 32;        // BF: k-steps of 32 own gate rows
     __shared__ __attribute__((aligned(16))) float dgl[16][DSTR];
     __shared__ __attribute__((aligned(16))) float part[NG][NI][4];
-    __shared__ int s_abort;
-    const int jt = blockIdx.x, d = blockIdx.y, bt = blockIdx.z, NJT = gridDim.x, NBT = gridDim.z;
+    __shared__ int s_abort, s_local;
+    // classic grid (NJT, 2, NBT), or the XCD-grouped one of the forward kernel (8 * NJT workgroups, label = id & 7)
+    int jt = blockIdx.x, d = blockIdx.y, bt = blockIdx.z, NJT = gridDim.x, NBT = gridDim.z;
+    if (xcd_nbt > 0) {
+        const int grp = blockIdx.x & 7;
+        if (grp >= 2 * xcd_nbt) return;
+        jt = blockIdx.x >> 3; d = grp & 1; bt = grp >> 1; NJT = gridDim.x >> 3; NBT = xcd_nbt;
+    }
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i = lane & 15, q = lane >> 4;
     const int j0 = jt * UW, b0 = bt * 16;
@@ -727,8 +770,30 @@ __global__ __launch_bounds__(256) void blstm_bwd_rs_kernel(
     float *xg = xP + ((int64_t)(d * NBT + bt) * 2) * slotf;
     __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(xg, 0, (int)(2 * slotf * 4), 0x00020000);
     unsigned *fl = flags + (d * NBT + bt) * NJT;
-    if (tid == 0) s_abort = 0;
+    if (tid == 0) { s_abort = 0; s_local = 0; }
     __syncthreads();
+    // XCD-grouped grid: plain exchange stores when the whole group reports one XCD (see the forward kernel)
+    if (xcd_nbt > 0) {
+        unsigned xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        xcc &= 0xffu;
+        unsigned *xid = flags + 512 + (d * NBT + bt) * 64;
+        if (tid == 0) __hip_atomic_store(xid + jt, (xcd_epoch << 8) | xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (wave == 0) {
+            unsigned v = 0;
+            bool ok = false;
+            for (int spins = 0; spins < (1 << 16); ++spins) {
+                v = lane < NJT ? __hip_atomic_load(xid + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : ((xcd_epoch << 8) | xcc);
+                ok = (v >> 8) == xcd_epoch;
+                if (__all(ok)) break;
+                __builtin_amdgcn_s_sleep(1);
+            }
+            const bool same = __all(ok && (v & 0xffu) == xcc);
+            if (lane == 0) s_local = same && !(dbg & 16);
+        }
+        __syncthreads();
+    }
+    const bool xlocal = s_local != 0;
 
     // Vector-memory issue order inside a step, as in the forward kernel (s_waitcnt vmcnt counts
     // loads and stores in issue order): exchange loads of the partial products  ->  this step's
@@ -846,7 +911,8 @@ __global__ __launch_bounds__(256) void blstm_bwd_rs_kernel(
                                    tag_bits(acc[mtl][3], e)};
                     }
                     const int64_t off = (s & 1) * slotf + (((int64_t)jt * MTILES + mt) * 16 + i) * 16 + 4 * q;
-                    __builtin_amdgcn_raw_buffer_store_b128(pk, rsrc, mt < MTILES ? (int)(off * 4) : OOB_OFF, 0, 16);
+                    if (xlocal) __builtin_amdgcn_raw_buffer_store_b128(pk, rsrc, mt < MTILES ? (int)(off * 4) : OOB_OFF, 0, 0);
+                    else __builtin_amdgcn_raw_buffer_store_b128(pk, rsrc, mt < MTILES ? (int)(off * 4) : OOB_OFF, 0, 16);
                 }
             }
         }
@@ -1051,13 +1117,14 @@ extern "C" int asr_blstm_precision(int mode) {
 template <int NT>
 static bool launch_fwd_persist_bf(int nks, dim3 grid, hipStream_t st, const float *W_hh, float *G, float *Cs,
                                   float *Hout, int64_t ho_t, int64_t ho_b, const int32_t *lengths, int T, int B,
-                                  int H, int s0, int s1, float *hx, unsigned *flags, unsigned *err) {
+                                  int H, int s0, int s1, float *hx, unsigned *flags, unsigned *err, int xcd_nbt = 0,
+                                  unsigned xcd_epoch = 0) {
     const int64_t hout_bytes = ((int64_t)(T - 1) * ho_t + (int64_t)(B - 1) * ho_b + 2 * H) * 4;
 #define FWD_BF_CASE(K)                                                                                       \
     case K:                                                                                                  \
         hipLaunchKernelGGL((blstm_fwd_persist_kernel<1, NT, K, true>), grid, dim3(256), 0, st, W_hh, G, Cs,  \
                            Hout, ho_t, ho_b, hout_bytes, lengths, T, B, H, s0, s1, hx, flags, err, g_dbg,    \
-                           g_tagmode);                                                                       \
+                           g_tagmode, xcd_nbt, xcd_epoch);                                                   \
         return true;
     switch (nks) { FWD_BF_CASE(1) FWD_BF_CASE(2) FWD_BF_CASE(3) FWD_BF_CASE(4) }
 #undef FWD_BF_CASE
@@ -1111,9 +1178,25 @@ extern "C" int asr_blstm_fwd_range(const float *W_hh, float *G, float *Cs, float
     }
     bool ok;
     const bool bf = blstm_precision() == 1 && H % 32 == 0 && H <= 512 && g_tagmode;
+    static int xcd_env = -1;
+    static unsigned xcd_epoch = 0;
+    if (xcd_env < 0) {
+        const char *e = getenv("ASR_BLSTM_XCD");
+        xcd_env = e ? atoi(e) : 2;
+    }
     if (bf && MT == 1) {
         ok = launch_fwd_persist_bf<1>(cdiv(H / 32, 4), dim3(NJ, 2, 1), st, W_hh, G, Cs, Hout, ho_t, ho_b, lengths, T, B,
                                       H, s0, s1, hx, flags, err);
+    } else if (bf && g_fwd_form == 0 && xcd_env && H % 16 == 0) {
+        // one (direction, batch tile) group of H/16 workgroups per XCD label, 16 hidden units per workgroup
+        xcd_epoch = (xcd_epoch + 1) & 0xffffffu;
+        if (xcd_epoch == 0) xcd_epoch = 1;
+        if (xcd_env == 2)      // experiment: 8 units per workgroup, H/8 workgroups per label (more than the XCD's 32 CUs at H = 320)
+            ok = launch_fwd_persist_bf<2>(cdiv(H / 32, 4), dim3(8 * (H / 8), 1, 1), st, W_hh, G, Cs, Hout, ho_t, ho_b, lengths,
+                                          T, B, H, s0, s1, hx, flags, err, MT, xcd_epoch);
+        else
+        ok = launch_fwd_persist_bf<4>(cdiv(H / 32, 4), dim3(8 * (H / 16), 1, 1), st, W_hh, G, Cs, Hout, ho_t, ho_b, lengths,
+                                      T, B, H, s0, s1, hx, flags, err, MT, xcd_epoch);
     } else if (bf && g_fwd_form == 0) {
         ok = launch_fwd_persist_bf<2>(cdiv(H / 32, 4), dim3(H / 8, 2, 2), st, W_hh, G, Cs, Hout, ho_t, ho_b, lengths, T,
                                       B, H, s0, s1, hx, flags, err);
@@ -1167,6 +1250,19 @@ extern "C" int asr_blstm_bwd_range(const float *W_hh, const float *W_hhT, float 
         if (njt <= 128 && njt * 2 * NBT <= 256 && 2 * NBT * njt <= BLSTM_FLAG_WORDS && xbytes < 0x7fffffff &&
             gbytes < (int64_t)0x7fff0000 && dho_t >= 0 && dho_b >= 0 && dh_bytes < (int64_t)0x7fff0000) {
             dim3 g2(njt, 2, NBT);
+            static int xcd_env = -1;
+            static unsigned xcd_epoch = 0;
+            if (xcd_env < 0) {
+                const char *e = getenv("ASR_BLSTM_XCD");
+                xcd_env = e ? atoi(e) : 1;
+            }
+            int xcd_nbt = 0;
+            if (xcd_env && g_tagmode && 2 * NBT <= 8 && NBT > 1 && njt <= 64) {   // one (direction, batch tile) group per XCD label
+                g2 = dim3(8 * njt, 1, 1);
+                xcd_nbt = NBT;
+                xcd_epoch = (xcd_epoch + 1) & 0xffffffu;
+                if (xcd_epoch == 0) xcd_epoch = 1;
+            }
             float *xP = ws + BLSTM_HX_OFF;
             bool launched = true;
             if (s0 == 0) {
@@ -1180,11 +1276,11 @@ extern "C" int asr_blstm_bwd_range(const float *W_hh, const float *W_hhT, float 
         if (bfb)                                                                                             \
             hipLaunchKernelGGL((blstm_bwd_rs_kernel<U, N, true>), g2, dim3(256), 0, st, W_hh, G, Cs, dHout,  \
                                dho_t, dho_b, lengths, dh_bytes, T, B, H, s0, s1, dc_ws, xP, flags, err,      \
-                               g_dbg, g_tagmode);                                                            \
+                               g_dbg, g_tagmode, xcd_nbt, xcd_epoch);                                        \
         else                                                                                                 \
             hipLaunchKernelGGL((blstm_bwd_rs_kernel<U, N>), g2, dim3(256), 0, st, W_hh, G, Cs, dHout, dho_t, \
                                dho_b, lengths, dh_bytes, T, B, H, s0, s1, dc_ws, xP, flags, err, g_dbg,      \
-                               g_tagmode);                                                                   \
+                               g_tagmode, xcd_nbt, xcd_epoch);                                               \
     } while (0)
             if (uw == 8) {
                 switch (nmt) {

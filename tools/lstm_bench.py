@@ -27,7 +27,7 @@ def bwd():
                       lengths.data_ptr(), dc.data_ptr(), T, B, H, ws.data_ptr(), st)
 for prec in (0, 1):
     lib.asr_blstm_precision(prec)
-    for dbg in (0, 1):
+    for dbg in (0, 1, 16):
         lib.asr_debug_set(dbg)
         G.copy_(G0)
         tf = time_kernel_events(fwd, 3)
