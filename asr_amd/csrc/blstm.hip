@@ -259,7 +259,7 @@ __global__ __launch_bounds__(256) void blstm_fwd_persist_kernel(
     float *__restrict__ Hout, int64_t ho_t, int64_t ho_b, int64_t hout_bytes,
     const int32_t *__restrict__ lengths, int T, int B, int H, int s0, int s1, float *hx, unsigned *flags,
     unsigned *err, int dbg, int tagmode, int xcd_nbt = 0, unsigned xcd_epoch = 0) {
-    static_assert(MT * NT == 2 || (MT == 1 && NT == 1) || (MT == 1 && NT == 4), "64, 128 or 256 owner threads");
+    static_assert(MT * NT == 2 || (MT == 1 && NT == 1), "128 (64) owner threads");
     constexpr int UN = 4 * NT;                               // hidden units per workgroup
     __shared__ float red[2][4][MT][NT][16][17];
     __shared__ int s_abort, s_local;
@@ -1114,6 +1114,30 @@ extern "C" int asr_blstm_precision(int mode) {
     return old;
 }
 
+// Grid of the persistent kernels at 17..32 batch rows: 1 = one (direction, batch tile) exchange group per XCD label
+// with the verified same-XCD hand-off (default), 0 = the three-dimensional grid with write-through stores only.
+// ASR_BLSTM_XCD = 0 | 1 sets the start-up value.  Results are bit-identical either way.
+static int g_blstm_xcd = -1;
+static int blstm_xcd_groups() {
+    if (g_blstm_xcd < 0) {
+        const char *e = getenv("ASR_BLSTM_XCD");
+        g_blstm_xcd = (e && atoi(e) == 0) ? 0 : 1;
+    }
+    return g_blstm_xcd;
+}
+extern "C" int asr_blstm_xcd_groups(int mode) {
+    const int old = blstm_xcd_groups();
+    if (mode == 0 || mode == 1) g_blstm_xcd = mode;
+    return old;
+}
+// stamp of a launch's XCD reports (24 bits, never 0): words left by an earlier launch do not count
+static unsigned blstm_xcd_epoch() {
+    static unsigned epoch = 0;
+    epoch = (epoch + 1) & 0xffffffu;
+    if (epoch == 0) epoch = 1;
+    return epoch;
+}
+
 template <int NT>
 static bool launch_fwd_persist_bf(int nks, dim3 grid, hipStream_t st, const float *W_hh, float *G, float *Cs,
                                   float *Hout, int64_t ho_t, int64_t ho_b, const int32_t *lengths, int T, int B,
@@ -1178,25 +1202,13 @@ extern "C" int asr_blstm_fwd_range(const float *W_hh, float *G, float *Cs, float
     }
     bool ok;
     const bool bf = blstm_precision() == 1 && H % 32 == 0 && H <= 512 && g_tagmode;
-    static int xcd_env = -1;
-    static unsigned xcd_epoch = 0;
-    if (xcd_env < 0) {
-        const char *e = getenv("ASR_BLSTM_XCD");
-        xcd_env = e ? atoi(e) : 2;
-    }
     if (bf && MT == 1) {
         ok = launch_fwd_persist_bf<1>(cdiv(H / 32, 4), dim3(NJ, 2, 1), st, W_hh, G, Cs, Hout, ho_t, ho_b, lengths, T, B,
                                       H, s0, s1, hx, flags, err);
-    } else if (bf && g_fwd_form == 0 && xcd_env && H % 16 == 0) {
-        // one (direction, batch tile) group of H/16 workgroups per XCD label, 16 hidden units per workgroup
-        xcd_epoch = (xcd_epoch + 1) & 0xffffffu;
-        if (xcd_epoch == 0) xcd_epoch = 1;
-        if (xcd_env == 2)      // experiment: 8 units per workgroup, H/8 workgroups per label (more than the XCD's 32 CUs at H = 320)
-            ok = launch_fwd_persist_bf<2>(cdiv(H / 32, 4), dim3(8 * (H / 8), 1, 1), st, W_hh, G, Cs, Hout, ho_t, ho_b, lengths,
-                                          T, B, H, s0, s1, hx, flags, err, MT, xcd_epoch);
-        else
-        ok = launch_fwd_persist_bf<4>(cdiv(H / 32, 4), dim3(8 * (H / 16), 1, 1), st, W_hh, G, Cs, Hout, ho_t, ho_b, lengths,
-                                      T, B, H, s0, s1, hx, flags, err, MT, xcd_epoch);
+    } else if (bf && g_fwd_form == 0 && blstm_xcd_groups() && H / 8 <= 64) {
+        // one (direction, batch tile) group of H/8 workgroups per XCD label (8 hidden units per workgroup)
+        ok = launch_fwd_persist_bf<2>(cdiv(H / 32, 4), dim3(8 * (H / 8), 1, 1), st, W_hh, G, Cs, Hout, ho_t, ho_b, lengths,
+                                      T, B, H, s0, s1, hx, flags, err, MT, blstm_xcd_epoch());
     } else if (bf && g_fwd_form == 0) {
         ok = launch_fwd_persist_bf<2>(cdiv(H / 32, 4), dim3(H / 8, 2, 2), st, W_hh, G, Cs, Hout, ho_t, ho_b, lengths, T,
                                       B, H, s0, s1, hx, flags, err);
@@ -1250,18 +1262,12 @@ extern "C" int asr_blstm_bwd_range(const float *W_hh, const float *W_hhT, float 
         if (njt <= 128 && njt * 2 * NBT <= 256 && 2 * NBT * njt <= BLSTM_FLAG_WORDS && xbytes < 0x7fffffff &&
             gbytes < (int64_t)0x7fff0000 && dho_t >= 0 && dho_b >= 0 && dh_bytes < (int64_t)0x7fff0000) {
             dim3 g2(njt, 2, NBT);
-            static int xcd_env = -1;
-            static unsigned xcd_epoch = 0;
-            if (xcd_env < 0) {
-                const char *e = getenv("ASR_BLSTM_XCD");
-                xcd_env = e ? atoi(e) : 1;
-            }
             int xcd_nbt = 0;
-            if (xcd_env && g_tagmode && 2 * NBT <= 8 && NBT > 1 && njt <= 64) {   // one (direction, batch tile) group per XCD label
+            unsigned xcd_epoch = 0;
+            if (blstm_xcd_groups() && g_tagmode && 2 * NBT <= 8 && NBT > 1 && njt <= 64) {   // one (direction, batch tile) group per XCD label
                 g2 = dim3(8 * njt, 1, 1);
                 xcd_nbt = NBT;
-                xcd_epoch = (xcd_epoch + 1) & 0xffffffu;
-                if (xcd_epoch == 0) xcd_epoch = 1;
+                xcd_epoch = blstm_xcd_epoch();
             }
             float *xP = ws + BLSTM_HX_OFF;
             bool launched = true;

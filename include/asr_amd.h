@@ -269,6 +269,12 @@ int64_t asr_blstm_ws_floats(int B, int H);
  * other shapes stay fp32).  Returns the previous mode; other values only query.  Start-up value: environment
  * variable ASR_BLSTM_PRECISION = f32 | bf16x3. */
 int asr_blstm_precision(int mode);
+/* Grid of the persistent recurrence kernels at 17..32 batch rows (no counterpart in the reference: a placement choice).
+ * 1 (default): one (direction, batch tile) exchange group per XCD, hand-off through that XCD's L2 with plain stores
+ * once the group has verified from HW_REG_XCC_ID that it shares an XCD (write-through stores otherwise); 0: the
+ * three-dimensional grid, write-through stores only.  Bit-identical results.  Returns the previous setting; other
+ * values only query.  Start-up value: environment variable ASR_BLSTM_XCD = 0 | 1. */
+int asr_blstm_xcd_groups(int mode);
 int asr_blstm_fwd(const float *W_hh, float *G, float *Cs, float *Hout,
                   int64_t ho_t, int64_t ho_b, const int32_t *lengths,
                   int T, int B, int H, float *ws, void *stream);

@@ -233,6 +233,47 @@ def test_blstm_vs_oracle(B, T, D, H, N, lens, blstm_mode):
     assert not persistent_error_flags()
 
 
+@pytest.mark.parametrize("B,T,H", [(32, 60, 320), (20, 33, 64), (32, 17, 512)])
+def test_blstm_xcd_grouped_grid_is_bit_identical(B, T, H):
+    """asr_blstm_xcd_groups: one exchange group per XCD label (hand-off through that XCD's L2 with plain stores once the
+    group has verified its placement) against the three-dimensional grid with write-through stores, through the C ABI:
+    same arithmetic in the same order, so G / Cs / Hout of the forward and dG of the backward must be bit-identical."""
+    from asr_amd import _lib
+    lib = _lib.load()
+    dev = _dev()
+    g = torch.Generator().manual_seed(B * 1000 + T + H)
+    W = (torch.randn(2, 4 * H, H, generator=g) * 0.08).to(dev)
+    WT = W.transpose(1, 2).contiguous()
+    G0 = torch.randn(T, B, 2, 4 * H, generator=g).to(dev)
+    dH = torch.randn(T, B, 2 * H, generator=g).to(dev)
+    lengths = torch.randint(1, T + 1, (B,), generator=g).to(torch.int32)
+    lengths[0] = T
+    lengths = lengths.to(dev)
+    st = torch.cuda.current_stream().cuda_stream
+    outs = []
+    old = lib.asr_blstm_xcd_groups(-1)
+    try:
+        for mode in (0, 1):
+            lib.asr_blstm_xcd_groups(mode)
+            ws = torch.zeros(int(lib.asr_blstm_ws_floats(B, H)), device=dev)
+            Gw, Cs, Hout = G0.clone(), torch.zeros(T, B, 2, H, device=dev), torch.zeros(T, B, 2 * H, device=dev)
+            dc = torch.zeros(2 * B * H, device=dev)
+            check = _lib.check
+            check(lib.asr_blstm_fwd(W.data_ptr(), Gw.data_ptr(), Cs.data_ptr(), Hout.data_ptr(), B * 2 * H, 2 * H,
+                                    lengths.data_ptr(), T, B, H, ws.data_ptr(), st))
+            fwd = (Gw.clone(), Cs.clone(), Hout.clone())
+            check(lib.asr_blstm_bwd(W.data_ptr(), WT.data_ptr(), Gw.data_ptr(), Cs.data_ptr(), dH.data_ptr(), B * 2 * H,
+                                    2 * H, lengths.data_ptr(), dc.data_ptr(), T, B, H, ws.data_ptr(), st))
+            torch.cuda.synchronize()
+            assert int(ws.view(torch.int32)[1024]) == 0          # no in-launch wait timed out
+            outs.append(fwd + (Gw.clone(),))
+    finally:
+        lib.asr_blstm_xcd_groups(old)
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+    assert torch.isfinite(outs[1][3]).all() and float(outs[1][2].abs().max()) > 0
+
+
 def test_persistent_and_stepwise_recurrence_agree(blstm_mode):
     """The one-launch-per-layer (in-launch hand-off) kernels against the
     one-launch-per-time-step kernels at the production width, ragged batch of 32;
