@@ -346,7 +346,6 @@ __global__ __launch_bounds__(256) void blstm_fwd_persist_kernel(
         __syncthreads();
     }
     const bool xlocal = s_local != 0;
-    if (!(dbg & 32)) __builtin_amdgcn_s_setprio(3);   // issue priority over co-resident waves of other kernels (side-stream GEMMs)
 
     // Order of the vector-memory instructions inside a step (s_waitcnt vmcnt counts loads AND
     // stores, in issue order, so whatever is issued before the exchange loads is waited for with
@@ -795,7 +794,6 @@ __global__ __launch_bounds__(256) void blstm_bwd_rs_kernel(
         __syncthreads();
     }
     const bool xlocal = s_local != 0;
-    if (!(dbg & 32)) __builtin_amdgcn_s_setprio(3);   // issue priority over co-resident waves of other kernels (side-stream GEMMs)
 
     // Vector-memory issue order inside a step, as in the forward kernel (s_waitcnt vmcnt counts
     // loads and stores in issue order): exchange loads of the partial products  ->  this step's
@@ -947,13 +945,6 @@ __global__ __launch_bounds__(256) void blstm_bwd_rs_kernel(
     // sources per thread group: NJT <= 4*NMT*(16/UW) and NG = 64/UW*... = 256/NI groups -> NMT loads each
     constexpr int CH = NMT;
     static_assert(CH <= 8, "exchange loads per lane");
-    // saved activations one step ahead, as in the forward kernel (cold in the training step)
-    Act a_next;
-    {
-        const int tn = d == 0 ? T - 1 - s : s;
-        const bool actn = valid && s < s1 && tn < len;
-        a_next = load_act(tn, actn, actn ? gate_offset(tn) : OOB_OFF);
-    }
     for (; s < s1; ++s) {
         const int t = d == 0 ? T - 1 - s : s;
         const bool act = valid && t < len;
@@ -985,12 +976,7 @@ __global__ __launch_bounds__(256) void blstm_bwd_rs_kernel(
             v[c] = ld4_sc1(rsrc, w < NJT ? off0 + (int)((int64_t)w * MTILES * 256 * 4) : OOB_OFF);
         }
         __builtin_amdgcn_sched_barrier(0);   // keep the issue order: loads return in order
-        const Act a = a_next;
-        {
-            const int sn = s + 1, tn = d == 0 ? T - 1 - sn : sn;
-            const bool actn = valid && sn < s1 && tn < len;
-            a_next = load_act(tn, actn, actn ? gate_offset(tn) : OOB_OFF);
-        }
+        const Act a = load_act(t, act, growb);
         store_saved();
         __builtin_amdgcn_sched_barrier(0);
         bool ok = true;
