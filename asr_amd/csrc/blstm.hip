@@ -375,6 +375,16 @@ __global__ __launch_bounds__(256) void blstm_fwd_persist_kernel(
     __amdgpu_buffer_rsrc_t rC = __builtin_amdgcn_make_buffer_rsrc(Cs, 0, (int)((int64_t)T * B * 2 * H * 4), 0x00020000);
     __amdgpu_buffer_rsrc_t rH = __builtin_amdgcn_make_buffer_rsrc(Hout, 0, (int)hout_bytes, 0x00020000);
     const int gstep = valid ? H * 4 : 0;
+    // Shadow lanes: the threads right behind the owners (no cell of their own) load the NEXT step's input-projection
+    // gates of the owner MT*NT*64 places before them and drop the values.  In the training step G is cold (164 MB per
+    // layer); the touch brings the lines into this CU's L1 / the XCD's L2 a step before the owner needs them.
+    const int sh = tid - MT * NT * 64;
+    const bool shadow = sh >= 0 && sh < MT * NT * 64 && !(dbg & 64);
+    const int sh_bi = b0 + sh / UN, sh_jo = jt * UN + sh % UN;
+    const bool sh_valid = shadow && sh_bi < B && sh_jo < H;
+    auto shadow_offset = [&](int t) -> int {
+        return (sh_valid && t >= 0 && t < T) ? (int)(((((int64_t)t * B + sh_bi) * 2 + d) * 4 * H + sh_jo) * 4) : OOB_OFF;
+    };
 
     auto gate_offset = [&](int t) -> int {
         return valid ? (int)(((((int64_t)t * B + bi) * 2 + d) * 4 * H + jo) * 4) : OOB_OFF;
@@ -435,7 +445,9 @@ __global__ __launch_bounds__(256) void blstm_fwd_persist_kernel(
         }
     };
 
-    int pace = BLSTM_PACE_START, calm = 0;     // paced first attempt of the exchange gather, see the loop
+    // timing experiments (asr_debug_set bits 12..27): thresholds of the pace rule, or a fixed pace
+    const int pace_up = ((dbg >> 12) & 15) ? ((dbg >> 12) & 15) : 3, pace_dn = (dbg >> 16) & 15, pace_fix = (dbg >> 20) & 0xff;
+    int pace = pace_fix ? pace_fix - 1 : BLSTM_PACE_START, calm = 0;     // paced first attempt of the exchange gather, see the loop
     int s = s0;
     if (s == 0) {   // first step of the layer: no recurrent term, nothing pending
         const int t = d == 0 ? 0 : T - 1;
@@ -489,9 +501,13 @@ __global__ __launch_bounds__(256) void blstm_fwd_persist_kernel(
                 a[m][f] = ld4_sc1(rsrc, k < H ? (pbase + (k / UN) * chunk + (m * 16 + i) * UN + k % UN) * 4 : OOB_OFF);
             }
         __builtin_amdgcn_sched_barrier(0);   // keep the issue order: loads return in order
+        {
+            const int so = shadow_offset(d == 0 ? s + 1 : T - 2 - s);
+            const int goff = owner ? growb : so, gst = owner ? gstep : (so == OOB_OFF ? 0 : H * 4);
 #pragma unroll
-        for (int g = 0; g < 4; ++g)
-            pre[g] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rG, growb + g * gstep, 0, 0));
+            for (int g = 0; g < 4; ++g)
+                pre[g] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rG, goff + g * gst, 0, 0));
+        }
         store_saved();
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -503,7 +519,8 @@ __global__ __launch_bounds__(256) void blstm_fwd_persist_kernel(
                 calm += __all(ok) ? 0 : 0x100;                 // high byte: failed first attempts of this window
                 if ((++calm & 0xff) == 16) {                   // every 16 steps: aim at 2..4 failures per window
                     const int fails = calm >> 8;
-                    pace = fails >= 3 ? min(pace + 1, BLSTM_PACE_MAX) : (fails == 0 ? max(pace - 1, 0) : pace);
+                    pace = fails >= pace_up ? min(pace + 1, BLSTM_PACE_MAX) : (fails <= pace_dn ? max(pace - 1, 0) : pace);
+                    if (pace_fix) pace = pace_fix - 1;
                     calm = 0;
                 }
             }
@@ -929,7 +946,12 @@ __global__ __launch_bounds__(256) void blstm_bwd_rs_kernel(
         return (valid && t < len) ? (int)(((((int64_t)t * B + b) * 2 + d) * 4 * H + j) * 4) : OOB_OFF;
     };
 
-    int pace = BLSTM_PACE_START, calm = 0;     // paced first attempt of the exchange gather
+    // Through the XCD's L2 a failed first attempt costs a short retry, not a trip through the fabric, and waiting first
+    // only loses time: no pacing then (alone 926 -> 857 us per launch, with cold data 1120 -> 983; in the step
+    // 1222 -> 1047 us; tools/lstm_cold.py).  The write-through form keeps the adaptive rule.
+    const int pace_up = ((dbg >> 12) & 15) ? ((dbg >> 12) & 15) : 3, pace_dn = (dbg >> 16) & 15;
+    const int pace_fix = ((dbg >> 20) & 0xff) ? ((dbg >> 20) & 0xff) : (xlocal ? 1 : 0);
+    int pace = pace_fix ? pace_fix - 1 : BLSTM_PACE_START, calm = 0;     // paced first attempt of the exchange gather
     int s = s0;
     if (s == 0) {   // first step: nothing to receive, nothing pending
         const int t = d == 0 ? T - 1 : 0;
@@ -1001,7 +1023,8 @@ __global__ __launch_bounds__(256) void blstm_bwd_rs_kernel(
                 calm += __all(ok) ? 0 : 0x100;                 // high byte: failed first attempts of this window
                 if ((++calm & 0xff) == 16) {                   // every 16 steps: aim at 2..4 failures per window
                     const int fails = calm >> 8;
-                    pace = fails >= 3 ? min(pace + 1, BLSTM_PACE_MAX) : (fails == 0 ? max(pace - 1, 0) : pace);
+                    pace = fails >= pace_up ? min(pace + 1, BLSTM_PACE_MAX) : (fails <= pace_dn ? max(pace - 1, 0) : pace);
+                    if (pace_fix) pace = pace_fix - 1;
                     calm = 0;
                 }
             }
@@ -1095,12 +1118,17 @@ extern "C" int64_t asr_blstm_ws_floats(int B, int H) {
 
 // timing experiments only (tools/lstm_bench.py): bit 0 skips the in-launch waits, bit 1 the
 // store drain -- results are then WRONG; never set by the product path.
-static int g_dbg = 0;
+static int g_dbg_init() {
+    const char *e = getenv("ASR_BLSTM_DEBUG");          // timing experiments only, see asr_debug_set
+    const int f = e ? (int)strtol(e, nullptr, 0) : 0;
+    return (f & 0xff) | (f & 0x0ffff000);
+}
+static int g_dbg = g_dbg_init();
 static int g_bwd_form = 0;   // bit 8 of the debug flags selects the older dG-exchange kernel (A/B timing)
 static int g_fwd_form = 0;   // bit 10: forward kernel with both batch tiles in one workgroup (A/B timing)
 static int g_tagmode = 1;    // bit 9 selects the flag protocol instead of the in-band epoch tags
 extern "C" void asr_debug_set(int flags) {
-    g_dbg = flags & 0xff;
+    g_dbg = (flags & 0xff) | (flags & 0x0ffff000);
     g_bwd_form = (flags >> 8) & 1;
     g_tagmode = ((flags >> 9) & 1) ? 0 : 1;
     g_fwd_form = (flags >> 10) & 1;

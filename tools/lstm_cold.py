@@ -38,10 +38,14 @@ def timed(fn, cold, n=5):
         tot += e0.elapsed_time(e1)
     return tot / n * 1e3
 G.copy_(G0); fwd(); bwd(); torch.cuda.synchronize()
-lib.asr_debug_set(int(os.environ.get("LSTM_DBG", "0")))
-for cold in (False, True, False, True):
-    G.copy_(G0)
-    tf = timed(fwd, cold)
-    tb = timed(bwd, cold)
-    print(f"{'cold' if cold else 'warm'}: fwd {tf:7.1f} us ({tf / T:.2f} per step)   bwd {tb:7.1f} us ({tb / T:.2f} per step)", flush=True)
+# LSTM_DBG: comma-separated asr_debug_set words (bits 12..15 / 16..19: thresholds of the pace rule, 20..27: fixed pace + 1)
+for word in [int(x, 0) for x in os.environ.get("LSTM_DBG", "0").split(",")]:
+    lib.asr_debug_set(word)
+    for cold in (False, True):
+        G.copy_(G0)
+        tf = timed(fwd, cold)
+        tb = timed(bwd, cold)
+        print(f"dbg {word:#x} {'cold' if cold else 'warm'}: fwd {tf:7.1f} us ({tf / T:.2f} per step)   bwd {tb:7.1f} us ({tb / T:.2f} per step)", flush=True)
+lib.asr_debug_set(0)
 print("err", int(ws.view(torch.int32)[1024]))
+
