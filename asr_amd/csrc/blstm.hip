@@ -253,12 +253,15 @@ __device__ __forceinline__ bool poll_flags(unsigned *flags, int n, unsigned want
 // BF: the products on the bf16 matrix pipe (bf16x3 split, MT == 1, H % 32 == 0): the exchanged h travels as
 // {hi:lo} words, W_hh sits in registers pre-split, k-step ks = wave + 4 f (32 wide) of the KQ4 = ceil(H/128) steps
 // of a wave; everything else -- tags, issue order, cell update -- is the fp32 kernel's.
-template <int MT, int NT, int KQ4, bool BF = false>
+// PROD: the product path's settings (no timing-experiment bits, in-band tags) are compile-time constants: every
+// run-time switch inside the step loop is a scalar branch between the loads and their waits.
+template <int MT, int NT, int KQ4, bool BF = false, bool PROD = false>
 __global__ __launch_bounds__(256) void blstm_fwd_persist_kernel(
     const float *__restrict__ W_hh, float *__restrict__ G, float *__restrict__ Cs,
     float *__restrict__ Hout, int64_t ho_t, int64_t ho_b, int64_t hout_bytes,
     const int32_t *__restrict__ lengths, int T, int B, int H, int s0, int s1, float *hx, unsigned *flags,
-    unsigned *err, int dbg, int tagmode, int xcd_nbt = 0, unsigned xcd_epoch = 0) {
+    unsigned *err, int dbg_arg, int tagmode_arg, int xcd_nbt = 0, unsigned xcd_epoch = 0) {
+    const int dbg = PROD ? 0 : dbg_arg, tagmode = PROD ? 1 : tagmode_arg;
     static_assert(MT * NT == 2 || (MT == 1 && NT == 1), "128 (64) owner threads");
     constexpr int UN = 4 * NT;                               // hidden units per workgroup
     __shared__ float red[2][4][MT][NT][16][17];
@@ -378,6 +381,7 @@ __global__ __launch_bounds__(256) void blstm_fwd_persist_kernel(
     // Shadow lanes: the threads right behind the owners (no cell of their own) load the NEXT step's input-projection
     // gates of the owner MT*NT*64 places before them and drop the values.  In the training step G is cold (164 MB per
     // layer); the touch brings the lines into this CU's L1 / the XCD's L2 a step before the owner needs them.
+    const int lead = ((dbg >> 24) & 15) ? ((dbg >> 24) & 15) : 1;      // steps ahead (timing experiments: bits 24..27)
     const int sh = tid - MT * NT * 64;
     const bool shadow = sh >= 0 && sh < MT * NT * 64 && !(dbg & 64);
     const int sh_bi = b0 + sh / UN, sh_jo = jt * UN + sh % UN;
@@ -446,7 +450,7 @@ __global__ __launch_bounds__(256) void blstm_fwd_persist_kernel(
     };
 
     // timing experiments (asr_debug_set bits 12..27): thresholds of the pace rule, or a fixed pace
-    const int pace_up = ((dbg >> 12) & 15) ? ((dbg >> 12) & 15) : 3, pace_dn = (dbg >> 16) & 15, pace_fix = (dbg >> 20) & 0xff;
+    const int pace_up = ((dbg >> 12) & 15) ? ((dbg >> 12) & 15) : 3, pace_dn = (dbg >> 16) & 15, pace_fix = (dbg >> 20) & 0xf;
     int pace = pace_fix ? pace_fix - 1 : BLSTM_PACE_START, calm = 0;     // paced first attempt of the exchange gather, see the loop
     int s = s0;
     if (s == 0) {   // first step of the layer: no recurrent term, nothing pending
@@ -502,7 +506,7 @@ __global__ __launch_bounds__(256) void blstm_fwd_persist_kernel(
             }
         __builtin_amdgcn_sched_barrier(0);   // keep the issue order: loads return in order
         {
-            const int so = shadow_offset(d == 0 ? s + 1 : T - 2 - s);
+            const int so = shadow_offset(d == 0 ? s + lead : T - 1 - lead - s);
             const int goff = owner ? growb : so, gst = owner ? gstep : (so == OOB_OFF ? 0 : H * 4);
 #pragma unroll
             for (int g = 0; g < 4; ++g)
@@ -723,12 +727,13 @@ __global__ __launch_bounds__(256) void blstm_bwd_persist_kernel(
 // MFMA operands never come from another workgroup.
 // BF: the products on the bf16 matrix pipe (bf16x3 split): W_hh's rows sit in registers as hi / lo fragments, the
 // workgroup's own dG goes through LDS as {hi:lo} words; the exchanged partial products stay fp32.
-template <int UW, int NMT, bool BF = false>
+template <int UW, int NMT, bool BF = false, bool PROD = false>
 __global__ __launch_bounds__(256) void blstm_bwd_rs_kernel(
     const float *__restrict__ W_hh, float *__restrict__ G, const float *__restrict__ Cs,
     const float *__restrict__ dHout, int64_t dho_t, int64_t dho_b, const int32_t *__restrict__ lengths,
     int64_t dh_bytes, int T, int B, int H, int s0, int s1, float *__restrict__ dc_ws, float *xP, unsigned *flags,
-    unsigned *err, int dbg, int tagmode, int xcd_nbt = 0, unsigned xcd_epoch = 0) {
+    unsigned *err, int dbg_arg, int tagmode_arg, int xcd_nbt = 0, unsigned xcd_epoch = 0) {
+    const int dbg = PROD ? 0 : dbg_arg, tagmode = PROD ? 1 : tagmode_arg;
     constexpr int KL = 4 * UW, KS = KL / 4, DSTR = KL + 4;
     constexpr int NI = 16 * UW / 4;     // 16-byte items per source workgroup (16 rows x UW/4)
     constexpr int NG = 256 / NI;        // thread groups that split the sources
@@ -950,7 +955,7 @@ __global__ __launch_bounds__(256) void blstm_bwd_rs_kernel(
     // only loses time: no pacing then (alone 926 -> 857 us per launch, with cold data 1120 -> 983; in the step
     // 1222 -> 1047 us; tools/lstm_cold.py).  The write-through form keeps the adaptive rule.
     const int pace_up = ((dbg >> 12) & 15) ? ((dbg >> 12) & 15) : 3, pace_dn = (dbg >> 16) & 15;
-    const int pace_fix = ((dbg >> 20) & 0xff) ? ((dbg >> 20) & 0xff) : (xlocal ? 1 : 0);
+    const int pace_fix = ((dbg >> 20) & 0xf) ? ((dbg >> 20) & 0xf) : (xlocal ? 1 : 0);
     int pace = pace_fix ? pace_fix - 1 : BLSTM_PACE_START, calm = 0;     // paced first attempt of the exchange gather
     int s = s0;
     if (s == 0) {   // first step: nothing to receive, nothing pending
@@ -1186,11 +1191,16 @@ static bool launch_fwd_persist_bf(int nks, dim3 grid, hipStream_t st, const floa
                                   int H, int s0, int s1, float *hx, unsigned *flags, unsigned *err, int xcd_nbt = 0,
                                   unsigned xcd_epoch = 0) {
     const int64_t hout_bytes = ((int64_t)(T - 1) * ho_t + (int64_t)(B - 1) * ho_b + 2 * H) * 4;
-#define FWD_BF_CASE(K)                                                                                       \
-    case K:                                                                                                  \
-        hipLaunchKernelGGL((blstm_fwd_persist_kernel<1, NT, K, true>), grid, dim3(256), 0, st, W_hh, G, Cs,  \
-                           Hout, ho_t, ho_b, hout_bytes, lengths, T, B, H, s0, s1, hx, flags, err, g_dbg,    \
-                           g_tagmode, xcd_nbt, xcd_epoch);                                                   \
+#define FWD_BF_CASE(K)                                                                                           \
+    case K:                                                                                                      \
+        if (g_dbg == 0 && g_tagmode == 1)                                                                        \
+            hipLaunchKernelGGL((blstm_fwd_persist_kernel<1, NT, K, true, true>), grid, dim3(256), 0, st, W_hh, G, \
+                               Cs, Hout, ho_t, ho_b, hout_bytes, lengths, T, B, H, s0, s1, hx, flags, err, 0, 1, \
+                               xcd_nbt, xcd_epoch);                                                              \
+        else                                                                                                     \
+            hipLaunchKernelGGL((blstm_fwd_persist_kernel<1, NT, K, true>), grid, dim3(256), 0, st, W_hh, G, Cs,  \
+                               Hout, ho_t, ho_b, hout_bytes, lengths, T, B, H, s0, s1, hx, flags, err, g_dbg,    \
+                               g_tagmode, xcd_nbt, xcd_epoch);                                                   \
         return true;
     switch (nks) { FWD_BF_CASE(1) FWD_BF_CASE(2) FWD_BF_CASE(3) FWD_BF_CASE(4) }
 #undef FWD_BF_CASE
@@ -1321,7 +1331,11 @@ extern "C" int asr_blstm_bwd_range(const float *W_hh, const float *W_hhT, float 
             const bool bfb = blstm_precision() == 1;
 #define RS_CASE(U, N)                                                                                        \
     do {                                                                                                     \
-        if (bfb)                                                                                             \
+        if (bfb && g_dbg == 0 && g_tagmode == 1)                                                             \
+            hipLaunchKernelGGL((blstm_bwd_rs_kernel<U, N, true, true>), g2, dim3(256), 0, st, W_hh, G, Cs,   \
+                               dHout, dho_t, dho_b, lengths, dh_bytes, T, B, H, s0, s1, dc_ws, xP, flags,    \
+                               err, 0, 1, xcd_nbt, xcd_epoch);                                               \
+        else if (bfb)                                                                                        \
             hipLaunchKernelGGL((blstm_bwd_rs_kernel<U, N, true>), g2, dim3(256), 0, st, W_hh, G, Cs, dHout,  \
                                dho_t, dho_b, lengths, dh_bytes, T, B, H, s0, s1, dc_ws, xP, flags, err,      \
                                g_dbg, g_tagmode, xcd_nbt, xcd_epoch);                                        \

@@ -49,3 +49,4 @@ for word in [int(x, 0) for x in os.environ.get("LSTM_DBG", "0").split(",")]:
 lib.asr_debug_set(0)
 print("err", int(ws.view(torch.int32)[1024]))
 
+
