@@ -769,7 +769,7 @@ struct PDParams {
 #define PD_NSTAMP 10
 #define PD_STAMP(i)                                                                                   \
     do {                                                                                              \
-        if (p.stamps != nullptr && tid == 0)                                                          \
+        if (STAMPS && p.stamps != nullptr && tid == 0)                                                \
             p.stamps[((int64_t)w * L + s) * PD_NSTAMP + (i)] = __builtin_amdgcn_s_memrealtime();      \
     } while (0)
 
@@ -830,6 +830,8 @@ static size_t attdec_persist_smem(int Tal) {
                                     2 * PD_WAVES * 16 * 17 + 16 * 17 + 32 + 16);
 }
 
+// STAMPS: the diagnostics build (tools/dec_stamps.py); the product path instantiates it without the ten per-step branches
+template <bool STAMPS>
 __global__ __launch_bounds__(PD_THREADS) void attdec_fwd_persist_kernel(PDParams p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const asr_attdec_fwd_args &a = p.a;
@@ -1385,7 +1387,9 @@ static int run_attdec_fwd(const asr_attdec_fwd_args *a, const GreedyParams *gp, 
             al16(a->g) && al16(a->sproj) && al16(a->ws)) {
             static thread_local bool attr3 = false;
             if (!attr3) {
-                ASR_CHECK_HIP(hipFuncSetAttribute((const void *)attdec_fwd_persist_kernel,
+                ASR_CHECK_HIP(hipFuncSetAttribute((const void *)attdec_fwd_persist_kernel<false>,
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+                ASR_CHECK_HIP(hipFuncSetAttribute((const void *)attdec_fwd_persist_kernel<true>,
                                                   hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
                 attr3 = true;
             }
@@ -1400,7 +1404,8 @@ static int run_attdec_fwd(const asr_attdec_fwd_args *a, const GreedyParams *gp, 
             p.stamps = g_attdec_stamps;
             // every exchanged float starts with the "wrong" epoch tag (LSB = 1)
             ASR_CHECK_HIP(hipMemsetAsync(p.xch, 0xFF, sizeof(float) * (size_t)xfl, st));
-            hipLaunchKernelGGL(attdec_fwd_persist_kernel, dim3((unsigned)nwg), dim3(PD_THREADS), psm, st, p);
+            if (p.stamps) hipLaunchKernelGGL(attdec_fwd_persist_kernel<true>, dim3((unsigned)nwg), dim3(PD_THREADS), psm, st, p);
+            else hipLaunchKernelGGL(attdec_fwd_persist_kernel<false>, dim3((unsigned)nwg), dim3(PD_THREADS), psm, st, p);
             ASR_CHECK_LAUNCH("attdec_fwd_persist_kernel");
             return ASR_OK;
         }
@@ -2226,6 +2231,7 @@ static size_t attdec_bwd_persist_smem() {
                                     4 * PD_AL + 2 * TT * 16 + 2 * PD_WAVES * 16 * 17 + 2 * PD_AL + 64);
 }
 
+template <bool STAMPS>
 __global__ __launch_bounds__(PD_THREADS) void attdec_bwd_persist_kernel(PBParams p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const asr_attdec_bwd_args &a = p.a;
@@ -2888,7 +2894,9 @@ extern "C" int asr_attdec_bwd(const asr_attdec_bwd_args *a, void *stream) {
             al16(a->dg) && al16(a->dsp) && al16(a->ws) && al16(f->sproj)) {
             static thread_local bool attr3 = false;
             if (!attr3) {
-                ASR_CHECK_HIP(hipFuncSetAttribute((const void *)attdec_bwd_persist_kernel,
+                ASR_CHECK_HIP(hipFuncSetAttribute((const void *)attdec_bwd_persist_kernel<false>,
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+                ASR_CHECK_HIP(hipFuncSetAttribute((const void *)attdec_bwd_persist_kernel<true>,
                                                   hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
                 attr3 = true;
             }
@@ -2917,7 +2925,8 @@ extern "C" int asr_attdec_bwd(const asr_attdec_bwd_args *a, void *stream) {
             p.err = reinterpret_cast<unsigned *>(a->ws + asr_attdec_bwd_err_offset(B, T, E, Hd, L));
             p.stamps = g_attdec_stamps;
             ASR_CHECK_HIP(hipMemsetAsync(p.xch, 0xFF, sizeof(float) * (size_t)xfl, st));
-            hipLaunchKernelGGL(attdec_bwd_persist_kernel, dim3((unsigned)nwg), dim3(PD_THREADS), psm, st, p);
+            if (p.stamps) hipLaunchKernelGGL(attdec_bwd_persist_kernel<true>, dim3((unsigned)nwg), dim3(PD_THREADS), psm, st, p);
+            else hipLaunchKernelGGL(attdec_bwd_persist_kernel<false>, dim3((unsigned)nwg), dim3(PD_THREADS), psm, st, p);
             ASR_CHECK_LAUNCH("attdec_bwd_persist_kernel");
             persistent = true;
         }
