@@ -38,8 +38,8 @@ XGMI_LINK_GBS = 153.0          # one xGMI link (7 per GPU)
 # HBM-side bytes per launch from the rocprofv3 PMC passes kept under profiles/ (FETCH_SIZE x 2: the gfx950
 # correction for 16-byte streams of MI355X_MICROARCH.md, + WRITE_SIZE), same kernels and shapes as here
 PMC_TRAFFIC = {                                      # profiles/r2_pmc_fetch_write.txt
-    "blstm_fwd": 2 * 486742e3 + 280000e3,
-    "blstm_bwd": 2 * 595221e3 + 958400e3,
+    "blstm_fwd": 2 * 83329e3 + 240165e3,             # after the XCD-grouped exchange (was 2 * 486742e3 + 280000e3)
+    "blstm_bwd": 2 * 100787e3 + 165567e3,            # (was 2 * 595221e3 + 958400e3)
     "attdec_fwd": 2 * 180997e3 + 166028e3,
     "attdec_bwd": 2 * 394285e3 + 249210e3,
     "ls_ce_config4": 2 * 66465e3 + 131470e3,
