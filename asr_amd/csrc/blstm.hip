@@ -975,11 +975,14 @@ __global__ __launch_bounds__(256) void blstm_bwd_rs_kernel(
     constexpr int CH = NMT;
     static_assert(CH <= 8, "exchange loads per lane");
     // saved activations one step ahead, as in the forward kernel (cold in the training step)
-    Act a_next;
+    Act a_next, a_next2;
     {
         const int tn = d == 0 ? T - 1 - s : s;
         const bool actn = valid && s < s1 && tn < len;
         a_next = load_act(tn, actn, actn ? gate_offset(tn) : OOB_OFF);
+        const int s2 = s + 1, tn2 = d == 0 ? T - 1 - s2 : s2;
+        const bool actn2 = valid && s2 < s1 && tn2 < len;
+        a_next2 = load_act(tn2, actn2, actn2 ? gate_offset(tn2) : OOB_OFF);
     }
     for (; s < s1; ++s) {
         const int t = d == 0 ? T - 1 - s : s;
@@ -1013,10 +1016,11 @@ __global__ __launch_bounds__(256) void blstm_bwd_rs_kernel(
         }
         __builtin_amdgcn_sched_barrier(0);   // keep the issue order: loads return in order
         const Act a = a_next;
+        a_next = a_next2;
         {
-            const int sn = s + 1, tn = d == 0 ? T - 1 - sn : sn;
+            const int sn = s + 2, tn = d == 0 ? T - 1 - sn : sn;
             const bool actn = valid && sn < s1 && tn < len;
-            a_next = load_act(tn, actn, actn ? gate_offset(tn) : OOB_OFF);
+            a_next2 = load_act(tn, actn, actn ? gate_offset(tn) : OOB_OFF);
         }
         store_saved();
         __builtin_amdgcn_sched_barrier(0);
