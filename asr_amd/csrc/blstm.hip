@@ -186,6 +186,7 @@ static int blstm_bwd_steps(const float *W_hhT, float *G, const float *Cs, const 
 // same way, so the grid always drains.
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 #define SPIN_LIMIT (1 << 21)
+#define BLSTM_FLAG_WORDS_ 1024   // = BLSTM_FLAG_WORDS (defined with the host dispatch)
 #define BLSTM_PACE_START 8     // initial wait before a step's first exchange gather, units of s_sleep 2
 #define BLSTM_PACE_MAX 40
 #define OOB_OFF 0x7ffffff0   // beyond every buffer here: the range check returns zeros
@@ -1096,6 +1097,19 @@ __global__ __launch_bounds__(256) void blstm_bwd_rs_kernel(
     if (s1 < T && valid) dc_ws[((int64_t)d * B + b) * H + j] = dcarry;   // picked up by the next launch
 }
 
+// One launch instead of two memsets before a persistent launch: zero the flag words, fill the exchange buffer with
+// 0xFF (every exchanged float starts with the "wrong" epoch tag, LSB = 1).  n16 = 16-byte pieces of the exchange.
+__global__ __launch_bounds__(256) void blstm_init_ws_kernel(unsigned *flags, int nflags, uint4 *xch, int64_t n16) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < nflags) flags[i] = 0u;
+    if (i < n16) xch[i] = make_uint4(0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu);
+}
+static void blstm_init_ws(unsigned *flags, void *xch, int64_t xch_bytes, hipStream_t st) {
+    const int64_t n16 = xch_bytes / 16, n = n16 > BLSTM_FLAG_WORDS_ ? n16 : BLSTM_FLAG_WORDS_;
+    hipLaunchKernelGGL(blstm_init_ws_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, flags, BLSTM_FLAG_WORDS_,
+                       static_cast<uint4 *>(xch), n16);
+}
+
 // ------------------------------------------------------------ host dispatch --
 #define BLSTM_FLAG_WORDS 1024   // zeroed before every launch (multiple of 16 bytes, start of ws)
 #define BLSTM_ERR_WORD 1024     // sticky: set by a kernel whose poll timed out
@@ -1252,9 +1266,8 @@ extern "C" int asr_blstm_fwd_range(const float *W_hh, float *G, float *Cs, float
     unsigned *err = flags + BLSTM_ERR_WORD;
     float *hx = ws + BLSTM_HX_OFF;
     if (s0 == 0) {
-        ASR_CHECK_HIP(hipMemsetAsync(flags, 0, sizeof(unsigned) * BLSTM_FLAG_WORDS, st));
-        if (g_tagmode)   // every exchanged float starts with the "wrong" epoch tag (LSB = 1)
-            ASR_CHECK_HIP(hipMemsetAsync(hx, 0xFF, sizeof(float) * (size_t)4 * NJ * MT * 64, st));
+        if (g_tagmode) blstm_init_ws(flags, hx, (int64_t)sizeof(float) * 4 * NJ * MT * 64, st);
+        else ASR_CHECK_HIP(hipMemsetAsync(flags, 0, sizeof(unsigned) * BLSTM_FLAG_WORDS, st));
     }
     bool ok;
     const bool bf = blstm_precision() == 1 && H % 32 == 0 && H <= 512 && g_tagmode;
@@ -1328,9 +1341,8 @@ extern "C" int asr_blstm_bwd_range(const float *W_hh, const float *W_hhT, float 
             float *xP = ws + BLSTM_HX_OFF;
             bool launched = true;
             if (s0 == 0) {
-                ASR_CHECK_HIP(hipMemsetAsync(flags, 0, sizeof(unsigned) * BLSTM_FLAG_WORDS, st));
-                if (g_tagmode)
-                    ASR_CHECK_HIP(hipMemsetAsync(xP, 0xFF, (size_t)xbytes * 2 * NBT, st));
+                if (g_tagmode) blstm_init_ws(flags, xP, (int64_t)xbytes * 2 * NBT, st);
+                else ASR_CHECK_HIP(hipMemsetAsync(flags, 0, sizeof(unsigned) * BLSTM_FLAG_WORDS, st));
             }
             const bool bfb = blstm_precision() == 1;
 #define RS_CASE(U, N)                                                                                        \
