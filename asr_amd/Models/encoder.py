@@ -278,9 +278,10 @@ class _BLSTMLayerFunction(torch.autograd.Function):
             dHout = dOut
         dc_ws = torch.empty(2 * B * H, **f32)
         W_hh = torch.cat([w_hh_f, w_hh_r], 0).view(2, 4 * H, H)
-        W_hhT = ops.transpose(W_hh)                # [2][H][4H] (step-wise kernels)
         ws = _persist_ws(lib, B, H, dev)
         wsp = 0 if ws is None else ws.data_ptr()
+        # [2][H][4H] for the step-wise kernels; the reduce-scatter form reads W_hh only: no transposition on its chain
+        W_hhT = ops.transpose(W_hh) if lib.asr_blstm_bwd_needs_transposed(T, B, H, ho_t, ho_b, int(ws is not None)) else W_hh
         dG = G.view(T * B, 8 * H)                  # becomes d loss / d pre-activation gates (0 at padding)
         need_dx = ctx.needs_input_grad[0]
         nch = PIPE_CHUNKS if (streams.ENABLED and PIPE_BWD and T >= PIPE_MIN_T and need_dx and not first) else 1

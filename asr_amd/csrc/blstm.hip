@@ -1306,6 +1306,25 @@ extern "C" int asr_blstm_fwd(const float *W_hh, float *G, float *Cs, float *Hout
 // Steps [s0, s1) of the backward recurrence (step s = frame T-1-s of the forward direction and
 // frame s of the reverse direction); a launch with s0 > 0 continues the previous one on the
 // same ws and dc_ws.
+// 1 if asr_blstm_bwd / asr_blstm_bwd_range will read W_hhT for this shape (the step-wise kernels and the dG-exchange
+// form do), 0 if the reduce-scatter form runs, which only reads W_hh: the caller may then pass W_hh in both places
+// and skip the transposition.  Mirrors the dispatch below; a call that does need W_hhT rejects W_hhT == W_hh.
+extern "C" int asr_blstm_bwd_needs_transposed(int T, int B, int H, int64_t dho_t, int64_t dho_b, int have_ws) {
+    const int NJT = cdiv(H, 16), NBT = cdiv(B, 16);
+    const int64_t gbytes = (int64_t)T * B * 8 * H * 4;
+    const bool persist = have_ws && NJT <= 128 && NJT * 2 * NBT <= 256 && 2 * NBT * NJT <= BLSTM_FLAG_WORDS &&
+                         gbytes < (int64_t)0x7fffffff;
+    if (!persist || g_bwd_form != 0) return 1;
+    const int uw = bwd_unit_width(B, H);
+    const int njt = cdiv(H, uw), nmt = cdiv(cdiv(H, 16), 4);
+    const int64_t xbytes = (int64_t)2 * njt * 16 * (cdiv(H, 16) * 16) * 4;
+    const int64_t dh_bytes = ((int64_t)(T - 1) * dho_t + (int64_t)(B - 1) * dho_b + 2 * H) * 4;
+    const bool rs = njt <= 128 && njt * 2 * NBT <= 256 && 2 * NBT * njt <= BLSTM_FLAG_WORDS && xbytes < 0x7fffffff &&
+                    gbytes < (int64_t)0x7fff0000 && dho_t >= 0 && dho_b >= 0 && dh_bytes < (int64_t)0x7fff0000 &&
+                    (uw == 8 ? (nmt >= 1 && nmt <= 6) : (nmt >= 4 && nmt <= 8));
+    return rs ? 0 : 1;
+}
+
 extern "C" int asr_blstm_bwd_range(const float *W_hh, const float *W_hhT, float *G, const float *Cs,
                                    const float *dHout, int64_t dho_t, int64_t dho_b, const int32_t *lengths,
                                    float *dc_ws, int T, int B, int H, int s0, int s1, float *ws, void *stream) {
@@ -1387,6 +1406,7 @@ extern "C" int asr_blstm_bwd_range(const float *W_hh, const float *W_hhT, float 
             }
         }
     }
+    ASR_CHECK_ARG(W_hhT != W_hh, "blstm_bwd: this shape needs the transposed W_hh (asr_blstm_bwd_needs_transposed)");
     dim3 grid(NJT, 2, NBT);
     if (!full) persist = false;   // the dG-exchange kernel (A/B timing only) runs whole layers
     if (persist) {

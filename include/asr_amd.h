@@ -307,6 +307,10 @@ int asr_blstm_fwd_noalloc(const float *W_hh, float *G, float *Cs, float *Hout,
  *   dc_ws [2][B][H] scratch
  * The weight/input gradients are plain GEMMs over G afterwards (asr_sgemm).
  */
+/* 1 if asr_blstm_bwd / asr_blstm_bwd_range read W_hhT for this shape, 0 if only W_hh is read (the reduce-scatter
+ * form): the caller may then pass W_hh in both places and skip the transposition (a 36 us kernel on the critical
+ * path of every layer at the config-2 size).  A call that does need W_hhT rejects W_hhT == W_hh. */
+int asr_blstm_bwd_needs_transposed(int T, int B, int H, int64_t dho_t, int64_t dho_b, int have_ws);
 int asr_blstm_bwd(const float *W_hh, const float *W_hhT, float *G, const float *Cs, const float *dHout,
                   int64_t dho_t, int64_t dho_b, const int32_t *lengths,
                   float *dc_ws, int T, int B, int H, float *ws, void *stream);
