@@ -100,3 +100,26 @@ def test_target_must_be_contiguous_like_the_reference():
     t = torch.zeros(2, 6, dtype=torch.long)[:, :4]
     with pytest.raises(RuntimeError, match="contiguous"):
         label_smoothing_loss(torch.zeros(2, 4, 5), t, torch.tensor([4, 4]))
+
+
+def test_host_side_dispatch_queries_and_split_k_rule():
+    """Host logic that needs no GPU: which backward form reads the transposed W_hh, the split-K rule of the weight
+    gradients (one resident round of 512 workgroups on 128x128 tiles), the readable span of GEMM operands."""
+    import torch
+    from asr_amd import _lib, ops
+    lib = _lib.load()
+    # config-2 layer, batch-major output strides: reduce-scatter form, W_hh only
+    assert lib.asr_blstm_bwd_needs_transposed(500, 32, 320, 640, 500 * 640, 1) == 0
+    assert lib.asr_blstm_bwd_needs_transposed(500, 32, 320, 640, 500 * 640, 0) == 1     # no workspace: step-wise kernels
+    assert lib.asr_blstm_bwd_needs_transposed(500, 512, 320, 640, 500 * 640, 1) == 1    # too many batch tiles for one launch
+    assert ops.pick_splitk(2048, 256, 11968) == 16          # Conformer ff dW: 32 tiles x 16 = 512 workgroups
+    assert ops.pick_splitk(2560, 640, 16000) == 5           # config-2 dW_ih, both directions: 100 tiles x 5
+    assert ops.pick_splitk(16000, 2560, 640) == 1
+    assert 1 <= ops.pick_splitk(256, 256, 11968) <= 64
+    t = torch.zeros(10, 8)
+    assert ops._span(t, 0, 10, 8, 0, 8, 0, 1, 0, 0, 0, False) == 80 * 4
+    assert ops._span(t, 16, 8, 8, 0, 8, 0, 1, 0, 0, 0, False) == 64 * 4
+    assert ops._span(t, 0, 11, 8, 0, 8, 0, 1, 0, 0, 0, False) == 0            # a row past the tensor
+    assert ops._span(t, 0, 8, 8, 4, 8, 1000, 1, 0, 0, 0, False) == 0          # two-level view into another allocation
+    assert ops._span(t, 0, 8, 8, 4, 8, 32, 1, 0, 0, 0, False) == 80 * 4       # two-level view inside the tensor
+    assert ops._span(t.t(), 0, 8, 10, 0, 10, 0, 1, 0, 0, 0, False) == 0       # not contiguous
