@@ -33,14 +33,18 @@ BN_MOMENTUM = 0.1
 # its tensor's largest entry.  With the subsampling's forward split too, its two conv weights land at 1.3e-3 / 3.1e-3:
 # a pre-activation that round-off moves across zero flips its ReLU mask, a whole term of a ~1e6-term, heavily
 # cancelling sum (fp32 against float64 shows the same effect at its own scale, tools/cnn_check.py).
-# ASR_CONFORMER_GEMM_PRECISION=f32 brings back exact products everywhere in this file.
-GEMM_PRECISION = os.environ.get("ASR_CONFORMER_GEMM_PRECISION", "bf16x3")
+# This file INHERITS the process-wide mode (ASR_GEMM_PRECISION / ops.gemm_precision, default bf16x3): a caller who
+# asked for the reference's exact fp32 products gets them here too.  ASR_CONFORMER_GEMM_PRECISION, only when set,
+# overrides the mode for this encoder alone (A/B runs).
+GEMM_PRECISION = os.environ.get("ASR_CONFORMER_GEMM_PRECISION")
 
 
 def _exact(fn):
-    """Run a forward / backward of this file under GEMM_PRECISION."""
+    """Run a forward / backward of this file under GEMM_PRECISION when that override is set."""
     @functools.wraps(fn)
     def wrapped(*a, **k):
+        if GEMM_PRECISION is None:
+            return fn(*a, **k)
         with ops.gemm_precision(GEMM_PRECISION):
             return fn(*a, **k)
     return wrapped

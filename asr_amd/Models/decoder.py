@@ -30,10 +30,27 @@ def _fill_fwd_args(a, dims, t):
         setattr(a, k, v.data_ptr())
 
 
+def batch_parts(lib, B, T, E, Hd, L):
+    """[(b0, b1), ...]: the batch as ONE part when the persistent loop kernels take it (asr_attdec_plan), else the
+    fewest equal parts that each do -- B x ceil(T/64) workgroups must each own a compute unit, which BASELINE config 4
+    (B = 32, T = 800: 416 workgroups) misses; utterances are independent inside the loop (Models/decoder.py:52-60), so
+    two launches of 16 utterances give the same numbers as one of 32.  One part as well when nothing fits: the
+    library then runs its four-launches-per-step loop over the whole batch."""
+    if lib.asr_attdec_plan(B, T, E, Hd, L) == 3:
+        return [(0, B)]
+    for n in range(2, min(B, 8) + 1):
+        bc = -(-B // n)
+        if lib.asr_attdec_plan(bc, T, E, Hd, L) == 3 and lib.asr_attdec_plan(B - bc * (n - 1), T, E, Hd, L) == 3:
+            return [(i * bc, min(B, (i + 1) * bc)) for i in range(n) if i * bc < B]
+    return [(0, B)]
+
+
 class _AttDecFunction(torch.autograd.Function):
     # parameter order (state_dict order of the reference's Decoder)
     NAMES = ("W_se", "W_he", "b_he", "w_ee", "W_fe", "conv_w",
              "W_sy", "W_gy", "b_gy", "W_yy", "b_yy", "Emb", "W_ss", "W_gs", "b_gs")
+    # gradients the backward produces on the side stream (asr_amd/streams.py); the others on the main stream
+    SIDE = ("W_gs", "W_ss", "b_gs", "W_gy", "W_sy", "b_gy", "W_se", "Emb", "W_he", "b_he")
 
     @staticmethod
     def forward(ctx, hbatch, lengths_dev, targets, *params):
@@ -41,6 +58,23 @@ class _AttDecFunction(torch.autograd.Function):
         P = dict(zip(_AttDecFunction.NAMES, params))
         hbatch = hbatch.contiguous()
         targets = targets.contiguous()
+        B, T, E = hbatch.shape
+        L = targets.shape[1]
+        Hd = P["W_sy"].shape[0]
+        V = P["W_yy"].shape[0]
+        Y = torch.empty(B, L, V, device=hbatch.device, dtype=torch.float32)
+        ctx.parts = []
+        for b0, b1 in batch_parts(lib, B, T, E, Hd, L):
+            t, U = _AttDecFunction._forward_part(lib, P, hbatch[b0:b1], lengths_dev[b0:b1], targets[b0:b1], Y[b0:b1])
+            ctx.parts.append((b0, b1, t, U))
+        ctx.dims = (B, T, E, Hd, L, V)
+        ctx.P = P
+        return Y
+
+    @staticmethod
+    def _forward_part(lib, P, hbatch, lengths_dev, targets, Y):
+        """The loop over one part of the batch (all of it, normally): hbatch, lengths, targets, Y are contiguous
+        row ranges of the caller's tensors."""
         B, T, E = hbatch.shape
         L = targets.shape[1]
         Hd = P["W_sy"].shape[0]
@@ -74,27 +108,44 @@ class _AttDecFunction(torch.autograd.Function):
         U = torch.empty(L, B, Hd, **f32)
         ops.linear_nt(g.view(L * B, E), P["W_gy"], U.view(L * B, Hd), bias1=P["b_gy"])
         ops.linear_nt(S[:L].view(L * B, Hd), P["W_sy"], U.view(L * B, Hd), accumulate=True, act=1)
-        Y = torch.empty(B, L, V, **f32)
         ops.sgemm(U, P["W_yy"], Y, B * L, V, Hd, a_two=(L, B * Hd, Hd), b_stride=Hd, c_stride=V,
                   bias1=P["b_yy"])
-        ctx.t = tensors
-        ctx.U = U
-        ctx.dims = (B, T, E, Hd, L, V)
-        ctx.P = P
-        return Y
+        return tensors, U
 
     @staticmethod
     def backward(ctx, dY):
         lib = _lib.load()
-        if ctx.t is None:
+        if ctx.parts is None:
             raise RuntimeError("asr_amd.Decoder: backward through the decoder a second time -- its saved "
                                "activations are released by the first pass (retain_graph is not supported)")
         B, T, E, Hd, L, V = ctx.dims
+        dY = dY.contiguous()
+        need_dh = ctx.needs_input_grad[0]
+        dh = torch.empty(B, T, E, device=dY.device, dtype=torch.float32) if need_dh else None
+        G = None
+        for b0, b1, t, U in ctx.parts:
+            Gp = _AttDecFunction._backward_part(lib, ctx.P, t, U, (b1 - b0, T, E, Hd, L, V), dY[b0:b1],
+                                                dh[b0:b1] if need_dh else None)
+            if G is None:
+                G = Gp
+                continue
+            # a further part of the batch: its weight gradients add to the first part's, each sum on the stream
+            # that produced its terms
+            side = [n for n in _AttDecFunction.NAMES if n in _AttDecFunction.SIDE]
+            main = [n for n in _AttDecFunction.NAMES if n not in _AttDecFunction.SIDE]
+            torch._foreach_add_([G[n] for n in main], [Gp[n] for n in main])
+            with streams.on_side(dY.device, *[Gp[n] for n in side], *[G[n] for n in side], params=tuple(ctx.P.values())):
+                torch._foreach_add_([G[n] for n in side], [Gp[n] for n in side])
+        ctx.parts = None
+        return (dh, None, None) + tuple(G[n] for n in _AttDecFunction.NAMES)
+
+    @staticmethod
+    def _backward_part(lib, P, t, U, dims, dY, dh):
+        """Gradients of one part of the batch: fills dh (when not None), returns the weight gradients by name."""
+        B, T, E, Hd, L, V = dims
         A = 2 * Hd
-        P, t, U = ctx.P, ctx.t, ctx.U
         dev = dY.device
         f32 = dict(device=dev, dtype=torch.float32)
-        dY = dY.contiguous()
         S, g, alpha, hbatch = t["S"], t["g"], t["alpha"], t["hbatch"]
         u_two = (L, B * Hd, Hd)          # row (b*L + l) of youtput  <->  row (l*B + b) of U
         G = {}
@@ -127,7 +178,7 @@ class _AttDecFunction(torch.autograd.Function):
         dconv = torch.empty(NC, 1, KW, **f32)
         ws = torch.empty(int(lib.asr_attdec_bwd_ws_floats(B, T, E, Hd, L)), **f32)
         a = AttDecBwdArgs()
-        _fill_fwd_args(a.f, ctx.dims, t)
+        _fill_fwd_args(a.f, dims, t)
         for k, v in dict(W_seT=W_seT, W_ssT=W_ssT, W_syT=W_syT, W_gsT=W_gsT, W_gyT=W_gyT, dyp=dyp, drec=drec,
                          dsp=dsp, dg=dg, de=de, dF=dF, dPH=dPH, dw_ee=dw_ee, dW_fe=dW_fe, dconv_w=dconv,
                          ws=ws).items():
@@ -140,9 +191,7 @@ class _AttDecFunction(torch.autograd.Function):
         h2 = hbatch.view(B * T, E)
         # critical path first: d hbatch = dPH W_he + sum_s alpha_s (x) dg_s  (per utterance:
         # (T x L) @ (L x E)) feeds the encoder backward
-        dh = None
-        if ctx.needs_input_grad[0]:
-            dh = torch.empty(B, T, E, **f32)
+        if dh is not None:
             ops.matmul_nn(dPH2, P["W_he"], dh.view(B * T, E))
             ops.sgemm(alpha, dg, dh, T, E, L, a_mode=1, a_stride=B * T, b_mode=1, b_stride=B * E, c_stride=E,
                       accumulate=True, nbatch=B, batch_a=T, batch_b=E, batch_c=T * E)
@@ -174,8 +223,8 @@ class _AttDecFunction(torch.autograd.Function):
             ops.colsum(dPH2, G["b_he"])
         G["w_ee"], G["W_fe"], G["conv_w"] = dw_ee, dW_fe, dconv
         G["W_yy"], G["b_yy"] = dW_yy, db_yy
-        ctx.t = ctx.U = None
-        return (dh, None, None) + tuple(G[n] for n in _AttDecFunction.NAMES)
+        assert set(_AttDecFunction.SIDE) | {"w_ee", "W_fe", "conv_w", "W_yy", "b_yy"} == set(_AttDecFunction.NAMES)
+        return G
 
 
 class Decoder(nn.Module):

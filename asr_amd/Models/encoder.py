@@ -339,6 +339,8 @@ class _BLSTMLayerFunction(torch.autograd.Function):
         with streams.on_side(dev, *side_reads, params=ctx.wparams):
             db = torch.empty(8 * H, **f32)
             ops.colsum(dG, db)                     # b_ih and b_hh receive the same column sums
+            if ws is not None:                     # a timed-out wait in this backward: NaN gradients NOW, not garbage
+                persist.poison_from(ws, db)
             for d in range(2):
                 # dW_hh[d] = sum_t dG_t^T h_{t-1}: forward pairs (t, t-1), reverse pairs (t, t+1);
                 # padded rows of dG and Hout are zero, so ragged lengths need no masking here

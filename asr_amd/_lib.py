@@ -108,6 +108,7 @@ SYMBOLS = {
     "asr_blstm_bwd_needs_transposed": (C.c_int, [C.c_int, C.c_int, C.c_int, c_i64, c_i64, C.c_int]),
     "asr_blstm_fwd": (C.c_int, [c_f, c_f, c_f, c_f, c_i64, c_i64, c_f, C.c_int, C.c_int, C.c_int, c_f, c_f]),
     "asr_blstm_fwd_noalloc_max_floats": (c_i64, []),
+    "asr_blstm_fwd_noalloc_err_word": (C.c_void_p, []),
     "asr_blstm_fwd_noalloc": (C.c_int, [c_f, c_f, c_f, c_f, c_i64, c_i64, c_f, C.c_int, C.c_int, C.c_int, c_f]),
     "asr_poison_if_flag": (C.c_int, [c_f, c_f, c_f]),
     "asr_stream_create": (C.c_int, [C.POINTER(C.c_void_p), c_f, C.c_int]),
@@ -122,6 +123,7 @@ SYMBOLS = {
     "asr_dropout_fwd": (C.c_int, [c_f, c_f, c_f, c_i64, C.c_float, C.c_uint64, c_f]),
     "asr_dropout_bwd": (C.c_int, [c_f, c_f, c_f, c_i64, C.c_float, c_f]),
     "asr_attdec_ws_floats": (c_i64, [C.c_int] * 5),
+    "asr_attdec_plan": (C.c_int, [C.c_int] * 5),
     "asr_attdec_fwd": (C.c_int, [C.POINTER(AttDecFwdArgs), c_f]),
     "asr_attdec_persist": (C.c_int, [C.c_int]),
     "asr_attdec_debug_stamps": (None, [c_f]),

@@ -751,6 +751,7 @@ static bool al16(const void *p) { return (((uintptr_t)p) & 15) == 0; }
 #define PD_WAVES (PD_THREADS / 64)
 #define PD_MTP 20          // 16-unit tiles of the attention dimension per wave (2 parts): A <= 640
 #define PD_HF 20           // frames per thread of the context chunk
+#define PD_HF_MAX 22       // ... of the forward instantiation for long utterances (T = 800: 39 frame groups x 21)
 #define PD_AL (32 * PD_MTP)   // attention units the LDS tables are padded to (zeros past A)
 #define PD_KF 5            // float4 per lane of a job's K slot: K <= 32 slots x 20 = 640
 #define PD_SPIN_LIMIT (1 << 20)
@@ -831,7 +832,8 @@ static size_t attdec_persist_smem(int Tal) {
 }
 
 // STAMPS: the diagnostics build (tools/dec_stamps.py); the product path instantiates it without the ten per-step branches
-template <bool STAMPS>
+// HF: frames per thread of the context chunk (PD_HF; PD_HF_MAX where T needs more than nfg * PD_HF frames)
+template <bool STAMPS, int HF>
 __global__ __launch_bounds__(PD_THREADS) void attdec_fwd_persist_kernel(PDParams p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const asr_attdec_fwd_args &a = p.a;
@@ -899,13 +901,13 @@ __global__ __launch_bounds__(PD_THREADS) void attdec_fwd_persist_kernel(PDParams
         }
     }
     // ---- context role: column chunk k of hbatch[b], frames fg + nfg i
-    float4 hreg[PD_HF];
+    float4 hreg[HF];
     {
         const int cg = tid % ncg, fg = tid / ncg;
         const bool cact = fg < nfg && c0 + 4 * cg < E;
         const float *hb = a.hbatch + (int64_t)b * T * E + c0 + 4 * cg;
 #pragma unroll
-        for (int i = 0; i < PD_HF; ++i) {
+        for (int i = 0; i < HF; ++i) {
             const int t = fg + nfg * i;
             const bool ok = cact && t < len;
             const float4 v = ld4(ok ? hb + (int64_t)t * E : a.hbatch);
@@ -1121,7 +1123,7 @@ __global__ __launch_bounds__(PD_THREADS) void attdec_fwd_persist_kernel(PDParams
                 float4 acc = zero4();
                 const float *ap = al_cur + fg;
 #pragma unroll
-                for (int i = 0; i < PD_HF; ++i) {
+                for (int i = 0; i < HF; ++i) {
                     const float av = ap[nfg * i];
                     acc.x += av * hreg[i].x; acc.y += av * hreg[i].y; acc.z += av * hreg[i].z; acc.w += av * hreg[i].w;
                 }
@@ -1307,6 +1309,21 @@ extern "C" int asr_attdec_persist(int on) {
     return old;
 }
 
+// Shape test of the one-launch forward (everything but pointer alignment): the frames-per-thread instantiation to
+// use (PD_HF or PD_HF_MAX), 0 when the shape does not fit -- B x ceil(T/64) workgroups must each get a compute unit.
+static int attdec_fwd_persist_hf(int B, int T, int E, int Hd, int n_cu) {
+    const int A = 2 * Hd, A16p = (A + 15) & ~15, NTILE = cdiv(T, TT), MTB = cdiv(B, 16);
+    const int NJ = cdiv(Hd, 4), NSP = cdiv(A, 16), EC = ((cdiv(E, NTILE) + 3) / 4) * 4, nfg = PD_THREADS / (EC / 4);
+    const int64_t nwg = (int64_t)B * NTILE;
+    const int hf = (int64_t)nfg * PD_HF >= T ? PD_HF : PD_HF_MAX;
+    const int Tal = (std::max(NTILE * TT, nfg * hf) + 3) & ~3;
+    const bool ok = A % 4 == 0 && E % 4 == 0 && Hd % 4 == 0 && energy_fwd2_smem(A) <= 150 * 1024 && A % 16 == 0 &&
+                    nwg <= n_cu && (int64_t)NJ * MTB <= nwg && (int64_t)NSP * MTB <= nwg && A16p <= 32 * PD_MTP &&
+                    E <= 128 * PD_KF && Hd <= 384 && EC / 4 <= PD_THREADS && (int64_t)nfg * hf >= T &&
+                    attdec_persist_smem(Tal) <= 150 * 1024 && attdec_ws_xch_floats(B, T, E, Hd) * 4 < (int64_t)0x7fff0000;
+    return ok ? hf : 0;
+}
+
 struct GreedyParams {
     const float *W_sy, *W_gy, *b_gy, *W_yy, *b_yy;
     int64_t *tokens;
@@ -1377,19 +1394,20 @@ static int run_attdec_fwd(const asr_attdec_fwd_args *a, const GreedyParams *gp, 
         p.nfg = PD_THREADS / (p.EC / 4);
         p.A16 = A16p;
         p.Tp = NTILE * TT;
-        p.Tal = (std::max(p.Tp, p.nfg * PD_HF) + 3) & ~3;
+        const int hf = attdec_fwd_persist_hf(B, T, E, Hd, n_cu);     // 0: the shape does not fit the one-launch form
+        p.Tal = (std::max(p.Tp, p.nfg * std::max(hf, PD_HF)) + 3) & ~3;
         const size_t psm = attdec_persist_smem(p.Tal);
         const int64_t xfl = attdec_ws_xch_floats(B, T, E, Hd);
         const int64_t nwg = (int64_t)B * NTILE;
-        if (attdec_persist_on() && !gp && use_v2 && vecH && vecS && vecG && A % 16 == 0 && nwg <= n_cu &&
-            (int64_t)p.NJ * MTB <= nwg && (int64_t)p.NSP * MTB <= nwg && A16p <= 32 * PD_MTP && E <= 128 * PD_KF && Hd <= 384 &&
-            p.EC / 4 <= PD_THREADS && (int64_t)p.nfg * PD_HF >= T && psm <= 150 * 1024 && xfl * 4 < (int64_t)0x7fff0000 &&
+        if (attdec_persist_on() && !gp && use_v2 && vecH && vecS && vecG && hf > 0 &&
             al16(a->g) && al16(a->sproj) && al16(a->ws)) {
             static thread_local bool attr3 = false;
             if (!attr3) {
-                ASR_CHECK_HIP(hipFuncSetAttribute((const void *)attdec_fwd_persist_kernel<false>,
+                ASR_CHECK_HIP(hipFuncSetAttribute((const void *)attdec_fwd_persist_kernel<false, PD_HF>,
                                                   hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-                ASR_CHECK_HIP(hipFuncSetAttribute((const void *)attdec_fwd_persist_kernel<true>,
+                ASR_CHECK_HIP(hipFuncSetAttribute((const void *)attdec_fwd_persist_kernel<true, PD_HF>,
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+                ASR_CHECK_HIP(hipFuncSetAttribute((const void *)attdec_fwd_persist_kernel<false, PD_HF_MAX>,
                                                   hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
                 attr3 = true;
             }
@@ -1404,8 +1422,9 @@ static int run_attdec_fwd(const asr_attdec_fwd_args *a, const GreedyParams *gp, 
             p.stamps = g_attdec_stamps;
             // every exchanged float starts with the "wrong" epoch tag (LSB = 1)
             ASR_CHECK_HIP(hipMemsetAsync(p.xch, 0xFF, sizeof(float) * (size_t)xfl, st));
-            if (p.stamps) hipLaunchKernelGGL(attdec_fwd_persist_kernel<true>, dim3((unsigned)nwg), dim3(PD_THREADS), psm, st, p);
-            else hipLaunchKernelGGL(attdec_fwd_persist_kernel<false>, dim3((unsigned)nwg), dim3(PD_THREADS), psm, st, p);
+            if (hf > PD_HF) hipLaunchKernelGGL((attdec_fwd_persist_kernel<false, PD_HF_MAX>), dim3((unsigned)nwg), dim3(PD_THREADS), psm, st, p);
+            else if (p.stamps) hipLaunchKernelGGL((attdec_fwd_persist_kernel<true, PD_HF>), dim3((unsigned)nwg), dim3(PD_THREADS), psm, st, p);
+            else hipLaunchKernelGGL((attdec_fwd_persist_kernel<false, PD_HF>), dim3((unsigned)nwg), dim3(PD_THREADS), psm, st, p);
             ASR_CHECK_LAUNCH("attdec_fwd_persist_kernel");
             return ASR_OK;
         }
@@ -2809,6 +2828,31 @@ extern "C" int64_t asr_attdec_bwd_err_offset(int B, int T, int E, int Hd, int L)
     return asr_attdec_bwd_ws_floats(B, T, E, Hd, L) - 64;
 }
 
+// Shape test of the one-launch backward (everything but pointer alignment), as attdec_fwd_persist_hf.
+static bool attdec_bwd_persist_ok(int B, int T, int E, int Hd, int n_cu) {
+    const int A = 2 * Hd, A16p = (A + 15) & ~15, MTB = cdiv(B, 16);
+    const int64_t nt = bwd_ntile(T), nwg = (int64_t)B * nt;
+    const int NJX = cdiv(Hd, 16), NJG = cdiv(E, 16), ECG = ((cdiv(E, 8) + 3) / 4) * 4, ECH = ((cdiv(A, (int)nt) + 3) / 4) * 4;
+    return A % 4 == 0 && Hd % 4 == 0 && energy_bwd2_smem(A) <= 150 * 1024 && A % 16 == 0 && E % 4 == 0 && nwg <= n_cu &&
+           (int64_t)(NJX + 2 * NJG) * MTB <= nwg && nwg <= PD_THREADS && A16p <= PD_AL && ECG <= 4 * PD_HF &&
+           2 * Hd <= 128 * PD_KF && nt * ECH <= 2 * PD_AL && nt * (ECH / 4) <= PD_THREADS && nt <= 64 &&
+           attdec_bwd_xch_floats(B, T, E, Hd) * 4 < (int64_t)0x7fff0000 && attdec_bwd_persist_smem() <= 150 * 1024;
+}
+
+// Which form asr_attdec_fwd / asr_attdec_bwd take for a shape on the current device, given 16-byte aligned tensors
+// (torch allocations are): bit 0 = the forward runs its L-step loop as one persistent launch, bit 1 = the backward
+// does.  0 with asr_attdec_persist(0).  The Python mirror splits a batch that is too large for one launch
+// (B x ceil(T/64) workgroups > compute units: BASELINE config 4, T = 800) into equal parts that each fit.
+extern "C" int asr_attdec_plan(int B, int T, int E, int Hd, int L) {
+    (void)L;
+    if (B <= 0 || T <= 0 || E <= 0 || Hd <= 0 || !attdec_persist_on()) return 0;
+    int dev = 0, n_cu = 0;
+    if (hipGetDevice(&dev) != hipSuccess ||
+        hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
+        return 0;
+    return (attdec_fwd_persist_hf(B, T, E, Hd, n_cu) > 0 ? 1 : 0) | (attdec_bwd_persist_ok(B, T, E, Hd, n_cu) ? 2 : 0);
+}
+
 extern "C" int asr_attdec_bwd(const asr_attdec_bwd_args *a, void *stream) {
     ASR_CHECK_ARG(a != nullptr, "attdec_bwd: null args");
     const asr_attdec_fwd_args *f = &a->f;
@@ -2888,9 +2932,7 @@ extern "C" int asr_attdec_bwd(const asr_attdec_bwd_args *a, void *stream) {
         const int64_t nwg = (int64_t)B * nt;
         const int64_t xfl = attdec_bwd_xch_floats(B, T, E, Hd);
         const size_t psm = attdec_bwd_persist_smem();
-        if (attdec_persist_on() && use_v2 && vecH && vecT && A % 16 == 0 && E % 4 == 0 && nwg <= n_cu &&
-            (int64_t)(p.NJX + 2 * p.NJG) * p.MTB <= nwg && nwg <= PD_THREADS && A16p <= PD_AL && p.ECG <= 4 * PD_HF && 2 * Hd <= 128 * PD_KF &&
-            nt * p.ECH <= 2 * PD_AL && nt * (p.ECH / 4) <= PD_THREADS && nt <= 64 && xfl * 4 < (int64_t)0x7fff0000 && psm <= 150 * 1024 &&
+        if (attdec_persist_on() && use_v2 && vecH && vecT && attdec_bwd_persist_ok(B, T, E, Hd, n_cu) &&
             al16(a->dg) && al16(a->dsp) && al16(a->ws) && al16(f->sproj)) {
             static thread_local bool attr3 = false;
             if (!attr3) {

@@ -1456,6 +1456,43 @@ static float *g_scratch_dev[BLSTM_STATIC_MAX_DEVICES];   // device address of bl
 
 extern "C" int64_t asr_blstm_fwd_noalloc_max_floats(void) { return BLSTM_STATIC_FLOATS; }
 
+// Device address of blstm_scratch on the device `stream` belongs to (the current device for the null
+// stream); taken once per device.  A stream of another device than the current one is rejected: the
+// symbol lookup and the launch below both act on the current device.
+static int blstm_noalloc_scratch(void *stream, float **out) {
+    int dev = -1;
+    ASR_CHECK_HIP(hipGetDevice(&dev));
+    if (stream != nullptr) {
+        hipDevice_t sdev = -1;
+        ASR_CHECK_HIP(hipStreamGetDevice(static_cast<hipStream_t>(stream), &sdev));
+        ASR_CHECK_ARG((int)sdev == dev, "blstm_fwd_noalloc: the stream belongs to device %d, the current device is %d",
+                      (int)sdev, dev);
+    }
+    ASR_CHECK_ARG(dev >= 0 && dev < BLSTM_STATIC_MAX_DEVICES, "blstm_fwd_noalloc: device %d out of range", dev);
+    float *ws = __atomic_load_n(&g_scratch_dev[dev], __ATOMIC_ACQUIRE);
+    if (ws == nullptr) {   // first call on this device (idempotent: racing threads store the same address)
+        void *p = nullptr;
+        ASR_CHECK_HIP(hipGetSymbolAddress(&p, HIP_SYMBOL(blstm_scratch)));
+        ASR_CHECK_ARG(p != nullptr, "blstm_fwd_noalloc: no device address for the scratch array");
+        ws = static_cast<float *>(p);
+        __atomic_store_n(&g_scratch_dev[dev], ws, __ATOMIC_RELEASE);
+    }
+    *out = ws;
+    return ASR_OK;
+}
+
+// The sticky error word of asr_blstm_fwd_noalloc on the current device (a device address inside the
+// static scratch; NULL on failure, see asr_last_error): non-zero after a launch whose in-kernel wait
+// timed out, in which case Hout / Cs of that call are garbage although the call returned ASR_OK (the
+// launch is asynchronous).  Hand it to asr_poison_if_flag on the same stream, as the workspace entry
+// points' callers do with word BLSTM_ERR_WORD of their workspace, or copy the 4 bytes back.  Sticky:
+// the library never clears it (the set-up of a call resets words 0 .. BLSTM_FLAG_WORDS-1 only).
+extern "C" const void *asr_blstm_fwd_noalloc_err_word(void) {
+    float *ws = nullptr;
+    if (blstm_noalloc_scratch(nullptr, &ws) != ASR_OK) return nullptr;
+    return reinterpret_cast<unsigned *>(ws) + BLSTM_ERR_WORD;
+}
+
 extern "C" int asr_blstm_fwd_noalloc(const float *W_hh, float *G, float *Cs, float *Hout, int64_t ho_t,
                                      int64_t ho_b, const int32_t *lengths, int T, int B, int H, void *stream) {
     ASR_CHECK_ARG(T > 0 && B > 0 && H > 0, "blstm_fwd_noalloc: bad shape T=%d B=%d H=%d", T, B, H);
@@ -1466,17 +1503,8 @@ extern "C" int asr_blstm_fwd_noalloc(const float *W_hh, float *G, float *Cs, flo
     ASR_CHECK_ARG(asr_blstm_ws_floats(B, H) >= 0 &&
                       BLSTM_HX_OFF + (int64_t)4 * cdiv(H, 4) * cdiv(B, 16) * 64 + 64 <= BLSTM_STATIC_FLOATS,
                   "blstm_fwd_noalloc: scratch too small for B=%d H=%d", B, H);
-    int dev = -1;
-    ASR_CHECK_HIP(hipGetDevice(&dev));
-    ASR_CHECK_ARG(dev >= 0 && dev < BLSTM_STATIC_MAX_DEVICES, "blstm_fwd_noalloc: device %d out of range", dev);
-    float *ws = __atomic_load_n(&g_scratch_dev[dev], __ATOMIC_ACQUIRE);
-    if (ws == nullptr) {   // first call on this device (idempotent: racing threads store the same address)
-        void *p = nullptr;
-        ASR_CHECK_HIP(hipGetSymbolAddress(&p, HIP_SYMBOL(blstm_scratch)));
-        ASR_CHECK_ARG(p != nullptr, "blstm_fwd_noalloc: no device address for the scratch array");
-        ws = static_cast<float *>(p);
-        __atomic_store_n(&g_scratch_dev[dev], ws, __ATOMIC_RELEASE);
-    }
+    float *ws = nullptr;
+    if (int rc = blstm_noalloc_scratch(stream, &ws)) return rc;
     // the persistent kernel only: its step-wise fallback would not need the scratch, but a caller of
     // this entry point asked for the one-launch path and must hear when it cannot have it
     const int kq4 = (cdiv(H, 16) + 3) / 4;

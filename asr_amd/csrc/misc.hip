@@ -420,10 +420,12 @@ extern "C" int asr_argmax_rows(const float *x, int64_t rows, int cols, int64_t l
 // ---------------------------------------------------------------------------
 // A HIP stream with a hardware queue of its own.  HIP multiplexes a process's streams onto
 // GPU_MAX_HW_QUEUES (4) hardware queues PER PRIORITY; the one exception is a stream created with a
-// compute-unit mask, which always gets a new queue.  asr_amd/streams.py runs the off-critical-path
-// work (weight-gradient GEMMs, bucket packing) on such a stream: a queue of its own at NORMAL
-// priority.  (Round 1 used a high-priority stream for the same purpose; a high-priority stream that
-// waits on an event of the normal-priority main stream can starve it -- tools/stall_probe.py.)
+// compute-unit mask, which always gets a new queue.  asr_amd/streams.py can run the off-critical-path
+// work (weight-gradient GEMMs, bucket packing) on such a stream (ASR_SIDE_STREAM_KIND=cumask); it is
+// NOT its default: measured, a stream created this way overlaps worse than a plain normal-priority
+// stream created before RCCL's, which is what streams.py uses.  (Round 1 used
+// a high-priority stream for the same purpose; a high-priority stream that waits on an event of the
+// normal-priority main stream can starve it -- tools/stall_probe.py.)
 // cu_mask: n_words x 32 bits, bit i = compute unit i enabled (NULL / 0 words: every CU).
 extern "C" int asr_stream_create(void **stream, const uint32_t *cu_mask, int n_words) {
     ASR_CHECK_ARG(stream != nullptr && n_words >= 0 && n_words <= 32, "stream_create: bad argument");

@@ -60,7 +60,10 @@ __global__ __launch_bounds__(256) void clip_adam_kernel(asr_tensor_list P, asr_t
     float coef = 1.f;
     if (max_norm > 0.f) {
         const float tn = sqrtf(norm2[0]);
-        coef = fminf(max_norm / (tn + 1e-6f), 1.0f);
+        // torch.clamp(clip_coef, max=1.0): a NaN norm (a poisoned gradient, asr_poison_if_flag) gives a NaN
+        // coefficient and with it NaN gradients and parameters, as clip_grad_norm_ does; fminf would drop it
+        const float c = max_norm / (tn + 1e-6f);
+        coef = c < 1.0f ? c : (c == c ? 1.0f : c);
     }
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)OPT_BLOCKS * 256) {
         const float pi = p[i];

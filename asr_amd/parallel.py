@@ -25,8 +25,15 @@ with the reducer, 33.6 without any).
 Differences from DistributedDataParallel, on purpose and checked:
 * one pass per ``finish()``: a second ``backward()`` before ``finish()`` raises (DDP would reduce each
   pass); accumulate micro-batches under ``no_sync()`` and let the last backward run outside it;
-* a parameter that received no gradient in the pass is reduced as zeros (every rank issues the same
-  collectives in the same order; DDP raises unless ``find_unused_parameters`` is set);
+* a parameter that received no gradient in the pass is reduced as zeros (DDP raises unless
+  ``find_unused_parameters`` is set).  Collectives are issued in BUCKET ORDER on every rank, whatever
+  order the gradients arrive in: a bucket whose gradients are complete is launched from the backward
+  only once every bucket before it has been launched, otherwise it waits for ``finish()``, which
+  launches the rest in order.  Ranks whose sets of unused parameters differ therefore still issue the
+  same sequence of all-reduces (tests/test_dp_gloo.py::test_unused_parameter_on_one_rank_only).  The
+  zero fill leaves ``p.grad`` a tensor of zeros (after the mean: the other ranks' average), not None:
+  an optimizer that skips ``grad is None`` parameters will now update them -- Adam applies its weight
+  decay and decays the moments of a parameter it would have left alone;
 * buffers (the Conformer's BatchNorm running statistics) are broadcast once by
   ``broadcast_parameters()``; DDP re-broadcasts them in every forward.  They do not enter the
   training-mode arithmetic; call ``broadcast_buffers()`` before a checkpoint or an evaluation pass
@@ -80,6 +87,13 @@ class BucketedGradReducer:
             warnings.warn("asr_amd.BucketedGradReducer: TORCH_NCCL_HIGH_PRIORITY=1 is set; a high-priority RCCL "
                           "stream that waits on this reducer's normal-priority streams can starve them and "
                           "the step never ends (see asr_amd/parallel.py) -- unset it")
+        dev0 = next((p.device for p in model.parameters() if p.is_cuda), None)
+        if (self.active and dev0 is not None and dist.get_backend(process_group) == "nccl"
+                and streams.KIND == "normal" and not streams.prepared(dev0)):
+            warnings.warn("asr_amd.BucketedGradReducer: the process group exists but asr_amd.streams.prepare(device) "
+                          "has not run; helper streams created from now on share the main stream's hardware queue "
+                          "and the weight-gradient / all-reduce overlap is lost (results are unaffected) -- call "
+                          "streams.prepare(device) before dist.init_process_group")
         # this reducer is stream-aware (see _launch): the weight gradients may be produced on the side stream
         self._streams_was = streams.ENABLED
         streams.enable(True)
@@ -109,6 +123,7 @@ class BucketedGradReducer:
                        and os.environ.get("ASR_GLOO_DEVICE_TENSORS", "0") != "1")
         self._hooks = []
         self._counts = [0] * len(self.buckets)
+        self._next = 0                          # buckets 0 .. _next-1 have been launched in this step
         self._where = {}
         self._sync = True
         self._closed = False
@@ -200,8 +215,11 @@ class BucketedGradReducer:
                                "reduced in this step; call finish() after every backward(), or accumulate "
                                "micro-batches under no_sync()")
         self._counts[bi] += 1
-        if self._counts[bi] == len(self.buckets[bi]):
-            self._launch(bi)
+        # one global launch order: bucket _next goes out as soon as it is complete, a later bucket
+        # that completes first waits for its turn (or for finish())
+        while self._next < len(self.buckets) and self._counts[self._next] == len(self.buckets[self._next]):
+            self._launch(self._next)
+            self._next += 1
 
     def _launch(self, bi):
         ps = self.buckets[bi]
@@ -240,12 +258,15 @@ class BucketedGradReducer:
         every bucket's collective, in bucket order: a parameter without a gradient is sent as zeros."""
         if not self.active:
             return
+        for bi in range(self._next, len(self.buckets)):
+            # not launched from the backward: hooks did not fire for (some of) the bucket -- unused parameter,
+            # gradients set by hand -- or an earlier bucket was incomplete
+            for p in self.buckets[bi]:
+                if p.grad is None:
+                    p.grad = torch.zeros_like(p)
+            self._launch(bi)
+        self._next = 0
         for bi, ps in enumerate(self.buckets):
-            if self.work[bi] is None:
-                for p in ps:       # hooks did not fire for (some of) the bucket: unused parameter, grads set by hand
-                    if p.grad is None:
-                        p.grad = torch.zeros_like(p)
-                self._launch(bi)
             self.work[bi].wait()
             flat = self.flat[bi]
             if flat.is_cuda:

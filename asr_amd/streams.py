@@ -27,16 +27,19 @@ def enable(flag=True):
 
 
 # How the helper streams are made (ASR_SIDE_STREAM_KIND):
-#   "cumask" (default): a stream created with a compute-unit mask (asr_stream_create) -- HIP gives such
+#   "normal" (DEFAULT): torch.cuda.Stream() -- one of the 4 normal-priority hardware queues.  Created by
+#       prepare() BEFORE the process group exists it owns its queue and overlaps the backward; created
+#       after RCCL's streams it shares the MAIN stream's queue and the overlap disappears (37.8 vs 35.4 ms
+#       per step; no error).  BucketedGradReducer warns when it finds the second situation.
+#   "cumask": a stream created with a compute-unit mask (asr_stream_create) -- HIP gives such
 #       a stream a hardware queue of its OWN, at normal priority.  ASR_SIDE_CU_MASK picks the CUs: "all"
 #       (default) or "hi:N" = the upper N compute units of every XCD (CU-mask bit i is compute unit i // 8
-#       of XCD i % 8 on MI355X), which keeps the weight-gradient GEMMs off N..31 only.
+#       of XCD i % 8 on MI355X), which keeps the weight-gradient GEMMs off N..31 only.  Measured slower
+#       than "normal" with every mask: A/B runs only.
 #   "priority": torch.cuda.Stream(priority=-1), round 1's way to a queue of its own.  A high-priority
 #       stream that waits on an event of the normal-priority main stream can starve it: with the stream
 #       created after RCCL's, the main stream's recurrence kernel never ran (tools/stall_probe.py,
 #       "plain" order) -- kept for A/B runs only.
-#   "normal": torch.cuda.Stream() -- shares one of 4 normal-priority hardware queues (after RCCL has
-#       created its streams: the MAIN stream's; the overlap then disappears, 37.8 vs 35.4 ms per step).
 KIND = os.environ.get("ASR_SIDE_STREAM_KIND", "normal")
 _streams = {}
 _pipes = {}
@@ -80,6 +83,11 @@ def _make(device):
             _lib.check(lib.asr_stream_create(C.byref(handle), C.cast(arr, C.c_void_p), len(words)))
     _owned.append((device.index, handle.value))
     return torch.cuda.ExternalStream(handle.value, device=device)
+
+
+def prepared(device):
+    """True once this device's helper streams exist (prepare(), or first use)."""
+    return device.index in _streams
 
 
 def prepare(device):

@@ -9,7 +9,15 @@ workload: BASELINE config 2: B=32 per GPU, 80-dim fbank,
           T_mel = linspace(1500, 900, 32), frame stacking 3 (T=500, D=240),
           5-layer BLSTM H=320, V=1000, L=100, fp32, synthetic N(0,1) features,
           random-init weights (seed 1234), inputs resident in HBM.
-Beside it, not part of `value`: `config5_conformer` = the same step for BASELINE config 5 (Conformer encoder).
+timing  : HIP events on the launch stream at every step boundary inside the timed region (one event per step);
+          `ms_per_step` = the MEDIAN step (SURVEY.md section 8d; max over ranks for N > 1), `value` = frames / that;
+          `ms_per_step_mean` = wall clock of the K steps / K (barrier + synchronize on both sides) beside it.
+dtype   : fp32 tensors and fp32 accumulation everywhere; the matrix products run as the bf16x3 split on the bf16
+          matrix pipe (three bf16 products per fp32 product, ~16 mantissa bits; include/asr_amd.h).  The same K steps
+          with exact fp32 products (asr_gemm_precision(0) + asr_blstm_precision(0)) are `ms_per_step_exact_f32`.
+Beside it, not part of `value`: `config5_conformer` = the same step for BASELINE config 5 (Conformer encoder),
+`config4_csj` = BASELINE config 4 (T = 800, L = 150, V = 7000) with the decoder path it took, `config1_speech_commands`
+(GPU step and the CPU leg on config 1, >= 5 steps), `ms_per_step_with_loss_item`.
 A "step" is one such pass over one batch.  For N > 1 there is one rank per GPU, each rank its
 own batch (weak scaling), gradients all-reduced in buckets on RCCL (asr_amd/parallel.py).  Under a
 launcher (WORLD_SIZE set: `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N`)
@@ -350,6 +358,134 @@ def config5_probe(dev, steps=5, warmup=2):
             "parameters": n_par, "loss": float(loss.detach())}
 
 
+def timed_steps(step, steps, warmup, sync_loss=False):
+    """warmup untimed calls of step(), then `steps` timed ones: per-step durations (ms) from HIP events recorded on
+    the current stream at every step boundary, and the wall clock of the whole region.  sync_loss: float(loss)
+    after every step, the reference's `print(loss.item())` (train.py:69-73)."""
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize()
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+    t0 = time.perf_counter()
+    evs[0].record()
+    loss = None
+    for i in range(steps):
+        loss = step()
+        if sync_loss:
+            float(loss)
+        evs[i + 1].record()
+    torch.cuda.synchronize()
+    wall = (time.perf_counter() - t0) * 1e3
+    per = [evs[i].elapsed_time(evs[i + 1]) for i in range(steps)]
+    return per, wall, loss
+
+
+def median(v):
+    v = sorted(v)
+    n = len(v)
+    return v[n // 2] if n % 2 else 0.5 * (v[n // 2 - 1] + v[n // 2])
+
+
+def config1_probe(dev, steps=5):
+    """BASELINE config 1 (speech_commands shape): lmfb 40, 98 mel frames, B=8, V=37, L=3,
+    stack 3 -> T=32, H=320 x 5.  The CPU leg (the oracle = stock-PyTorch restatement, >= 5 steps after one warm-up,
+    BASELINE.md section 3) beside the same step on the GPU."""
+    from asr_amd.Loss.label_smoothing import label_smoothing_loss
+    from asr_amd.Models.AttModel import AttModel
+    from oracle import ref_model as R
+    hp = make_hp(lmfb_dim=40, num_classes=37, encoder_dropout=0.0)
+    B, Tm, L = 8, 98, 3
+    g = torch.Generator().manual_seed(1234)
+    mel = torch.randn(B, Tm, 40, generator=g)
+    x = mel[:, : (Tm // 3) * 3].reshape(B, Tm // 3, -1).contiguous()
+    lengths = torch.full((B,), Tm // 3, dtype=torch.int64)
+    tgt = torch.randint(0, 37, (B, L), generator=g)
+    tl = torch.full((B,), L, dtype=torch.int64)
+    frames = B * Tm
+    threads = min(os.cpu_count() or 1, int(os.environ.get("OMP_NUM_THREADS", "16")), 16)
+    torch.set_num_threads(threads)
+    torch.manual_seed(1234)
+    ref = R.AttModel(hp).train()
+
+    def cpu_step():
+        ref.zero_grad(set_to_none=True)
+        loss = R.label_smoothing_loss(ref(x, lengths, tgt), tgt, tl, hp.T_norm, hp.B_norm)
+        loss.backward()
+        return loss
+    cpu_step()
+    cpu_ms = []
+    for _ in range(steps):
+        t0 = time.perf_counter()
+        lc = cpu_step()
+        cpu_ms.append((time.perf_counter() - t0) * 1e3)
+    m = AttModel(hp)
+    m.load_state_dict(ref.state_dict())
+    m = m.to(dev).train()
+    xd, td, tld = x.to(dev), tgt.to(dev), tl.to(dev)
+
+    def gpu_step():
+        m.zero_grad(set_to_none=True)
+        loss = label_smoothing_loss(m(xd, lengths, td), td, tld, hp.T_norm, hp.B_norm)
+        loss.backward()
+        return loss
+    per, _, lg = timed_steps(gpu_step, 20, 5)
+    return {"workload": "BASELINE config 1: B=8, 98 mel frames x 40, stack 3 -> T=32, 5xBLSTM 320, V=37, L=3, same weights",
+            "mel_frames": frames,
+            "cpu": {"kind": "port", "cores": threads, "steps": steps, "ms_per_step_median": median(cpu_ms),
+                    "ms_per_step": cpu_ms, "frames_per_s": frames / (median(cpu_ms) * 1e-3), "loss": float(lc.detach())},
+            "gpu": {"steps": 20, "ms_per_step_median": median(per), "frames_per_s": frames / (median(per) * 1e-3),
+                    "loss": float(lg.detach())},
+            "loss_rel_diff": abs(float(lg.detach()) - float(lc.detach())) / abs(float(lc.detach()))}
+
+
+def config4_probe(dev, steps=6, warmup=3):
+    """BASELINE config 4 (CSJ shape): lmfb 40 -> D_in 120, V=7000, B=32, T_mel linspace(2400,
+    1200) -> T=800, L=150; forward + label-smoothed CE + backward, dropout 0.2.  Reports which decoder path ran:
+    416 (b, 64-frame tile) workgroups do not fit 256 compute units, so the decoder loop runs as two persistent
+    launches of 16 utterances each (asr_amd/Models/decoder.py::batch_parts); `per_step_decoder_ms_per_step` is the
+    same step on the four-launches-per-label-step loop (asr_attdec_persist(0)), the path this shape took before."""
+    from asr_amd import _lib, streams
+    from asr_amd.Loss.label_smoothing import label_smoothing_loss
+    from asr_amd.Models.AttModel import AttModel
+    from asr_amd.Models.decoder import batch_parts
+    lib = _lib.load()
+    hp = make_hp(lmfb_dim=40, num_classes=7000)
+    torch.manual_seed(1234)
+    m = AttModel(hp).to(dev).train()
+    x, lengths, tgt, tl = make_batch(hp, dev, seed=1234, B=32, t_hi=2400, t_lo=1200, L=150, l_lo=75)
+    frames = int(torch.linspace(2400, 1200, 32).long().sum())
+    T, E, Hd, L = x.shape[1], 2 * hp.num_hidden_nodes_encoder, hp.num_hidden_nodes_decoder, 150
+    parts = batch_parts(lib, 32, T, E, Hd, L)
+    plan = [int(lib.asr_attdec_plan(b1 - b0, T, E, Hd, L)) for b0, b1 in parts]
+
+    def step():
+        for p in m.parameters():
+            p.grad = None
+        loss = label_smoothing_loss(m(x, lengths, tgt), tgt, tl, hp.T_norm, hp.B_norm)
+        loss.backward()
+        return loss
+
+    was = streams.ENABLED
+    streams.enable(True)
+    try:
+        per, _, loss = timed_steps(step, steps, warmup)
+        old = lib.asr_attdec_persist(0)
+        try:
+            per0, _, _ = timed_steps(step, max(3, steps // 2), 2)
+        finally:
+            lib.asr_attdec_persist(old)
+    finally:
+        streams.enable(was)
+    ms = median(per)
+    return {"workload": "BASELINE config 4 (CSJ): B=32, T_mel linspace(2400,1200) x 40, stack 3 -> T=800, D=120, "
+                        "5xBLSTM 320, V=7000, L=150, dropout 0.2",
+            "ms_per_step": ms, "frames_per_s": frames / (ms * 1e-3), "steps": steps, "warmup": warmup,
+            "decoder_path": ("persistent loop kernels, %d launch(es) per pass over batch parts %s" % (len(parts), parts)
+                             if all(v == 3 for v in plan) else "four launches per label step (fallback)"),
+            "attdec_plan": plan,
+            "per_step_decoder_ms_per_step": median(per0), "loss": float(loss.detach())}
+
+
 def start_watchdog(rank, dev):
     """Rehearsal diagnostics: every 20 s one line per rank saying whether the device still retires work
     (stream queries never block), so a stalled run names the rank and the stream that sit still."""
@@ -366,6 +502,34 @@ def start_watchdog(rank, dev):
             print(f"[bench rank {rank}] watchdog {20 * n:4d} s: main stream idle={main.query()} "
                   f"side stream idle={side.query() if side is not None else None}", file=sys.stderr, flush=True)
     threading.Thread(target=loop, daemon=True).start()
+
+
+N1_FILE = os.path.join(os.environ.get("TMPDIR", "/tmp"), "asr_amd_bench_n1.json")
+
+
+def n1_store(ms):
+    """An N = 1 run leaves its ms_per_step where an N > 1 run on the same host can find it."""
+    try:
+        with open(N1_FILE, "w") as f:
+            json.dump({"ms_per_step": ms, "time": time.time(), "host": os.uname().nodename}, f)
+    except OSError:
+        pass
+
+
+def n1_reference():
+    """(ms_per_step at N = 1, where it came from) for the N > 1 line's `scaling_efficiency_vs`: environment variable
+    ASR_BENCH_N1_MS, else what an N = 1 run of this bench left on this host within the last two hours."""
+    v = os.environ.get("ASR_BENCH_N1_MS")
+    if v:
+        return float(v), "ASR_BENCH_N1_MS"
+    try:
+        with open(N1_FILE) as f:
+            d = json.load(f)
+        if d.get("host") == os.uname().nodename and time.time() - d["time"] < 7200:
+            return float(d["ms_per_step"]), f"{N1_FILE} ({int(time.time() - d['time'])} s old)"
+    except (OSError, ValueError, KeyError):
+        pass
+    return None
 
 
 def free_port():
@@ -430,12 +594,20 @@ def stub_rank(args):
         per_rank = [None] * world
         dist.all_gather_object(per_rank, dt / args.steps * 1e3)
         mean_ok = all(bool(torch.allclose(p.grad, torch.full_like(p, (world + 1) / 2.0))) for p in model.parameters())
+        ar = reducer.allreduce_probe(iters=2)            # collective: every rank
         if rank == 0:
-            print(json.dumps({"metric": "stub", "value": 0.0, "unit": "frames/s", "n_gpus": world,
-                              "rccl_ranks": dist.get_world_size(), "steps": args.steps, "warmup": args.warmup,
-                              "ms_per_step": max(per_rank), "per_rank_ms": per_rank, "data": "stub",
-                              "allreduce_bytes_per_step": reducer.bytes_per_step(), "mean_ok": mean_ok,
-                              "gpus_arg": args.gpus}), flush=True)
+            res = {"metric": "stub", "value": 0.0, "unit": "frames/s", "n_gpus": world,
+                   "rccl_ranks": dist.get_world_size(), "backend": dist.get_backend(), "steps": args.steps,
+                   "warmup": args.warmup, "ms_per_step": max(per_rank), "per_rank_ms": per_rank, "data": "stub",
+                   "allreduce_bytes_per_step": reducer.bytes_per_step(), "mean_ok": mean_ok, "gpus_arg": args.gpus,
+                   "allreduce_buckets": ar}
+            tot_b, tot_s = sum(a["bytes"] for a in ar), sum(a["us"] for a in ar) * 1e-6
+            res["allreduce_bus_GBs"] = tot_b / tot_s / 1e9 * 2.0 * (world - 1) / world
+            n1 = n1_reference()
+            if n1 is not None:
+                res["scaling_efficiency_vs"] = {"n1_ms_per_step": n1[0], "source": n1[1],
+                                                "efficiency": n1[0] / max(per_rank)}
+            print(json.dumps(res), flush=True)
     dist.destroy_process_group()
     return 0
 
@@ -447,6 +619,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-config5", action="store_true", help="skip the Conformer (config 5) side measurement")
+    ap.add_argument("--no-config4", action="store_true", help="skip the CSJ-shape (config 4) side measurement")
     ap.add_argument("--dropout", type=float, default=0.2, help="encoder dropout (template default 0.2)")
     ap.add_argument("--rehearsal", action="store_true",
                     help="N ranks share GPU 0 over gloo: the N-rank code path on a 1-GPU box (not a throughput claim)")
@@ -550,11 +723,18 @@ def main():
         log(f'warm-up step {i} enqueued')
     barrier()
     log('warm-up done')
+    # the timed region: EXACTLY args.steps steps between two barrier + synchronize pairs; one HIP event per step
+    # boundary on the launch stream (a step ends with the side stream joined and the reducer finished on it)
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    evs[0].record()
+    for i in range(args.steps):
         loss = step()
+        evs[i + 1].record()
     barrier()
     dt = time.perf_counter() - t0
+    step_ms = [evs[i].elapsed_time(evs[i + 1]) for i in range(args.steps)]
+    med_ms = median(step_ms)
     # the recurrence kernels are timed IN the step, in a pass of their own behind the timed region: HIP events on the
     # launch stream round every asr_blstm_fwd / asr_blstm_bwd call (one launch per layer).  Inside the timed region the
     # 20 event records per step cost 0.3-0.6 ms of it (each one is a barrier packet between two dependent launches).
@@ -570,20 +750,35 @@ def main():
     if _enc.persistent_error_flags():
         raise SystemExit("bench.py: a persistent recurrence kernel reported a timed-out in-launch wait; "
                          "the run is invalid")
-    per_rank_ms = [dt / args.steps * 1e3]
+    per_rank_ms = [med_ms]
     if world > 1:
         import torch.distributed as dist
         per_rank_ms = [None] * world
-        dist.all_gather_object(per_rank_ms, dt / args.steps * 1e3)
-        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_gather_object(per_rank_ms, med_ms)
+        tt = torch.tensor([dt, med_ms], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt)
+        dt, med_ms = float(tt[0]), float(tt[1])
         ft = torch.tensor([frames], device=dev, dtype=torch.float64)
         dist.all_reduce(ft, op=dist.ReduceOp.SUM)
         total_frames = float(ft)
     else:
         total_frames = float(frames)
-    ms = dt / args.steps * 1e3
+    mean_ms = dt / args.steps * 1e3
+    ms = med_ms
+
+    # the same K steps with exact fp32 products everywhere (the reference's arithmetic, Models/encoder.py:25-26),
+    # and with the reference's per-step `loss.item()` host sync (train.py:69-73)
+    exact_ms = item_ms = None
+    if world == 1:
+        from asr_amd import _lib as _l
+        lib_ = _l.load()
+        og, ob = lib_.asr_gemm_precision(0), lib_.asr_blstm_precision(0)
+        try:
+            exact_ms = median(timed_steps(step, args.steps, 3)[0])
+        finally:
+            lib_.asr_gemm_precision(og)
+            lib_.asr_blstm_precision(ob)
+        item_ms = median(timed_steps(step, args.steps, 2, sync_loss=True)[0])
 
     # full optimiser step (clip + Adam, train.py:60-63), reported beside the metric: with the fused
     # asr_amd.optim.ClipAdam, and with the reference's stock clip_grad_norm_ + torch.optim.Adam
@@ -617,8 +812,15 @@ def main():
             "value": total_frames / (ms * 1e-3),
             "unit": "frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32 storage + accumulate, bf16x3 products (3 bf16 MFMA products per fp32 product)",
             "data": "synthetic",
+            "ms_per_step_is": "median of the per-step HIP-event durations of the timed region (max over ranks)",
+            "ms_per_step_mean": mean_ms, "value_from_mean": total_frames / (mean_ms * 1e-3),
+            "ms_per_step_min_max": [min(step_ms), max(step_ms)],
+            "ms_per_step_exact_f32": exact_ms,
+            "value_exact_f32": (total_frames / (exact_ms * 1e-3)) if exact_ms else None,
+            "ms_per_step_with_loss_item": item_ms,
             "config": {"workload": "BASELINE config 2: B=32/GPU, T_mel linspace(1500,900), stack 3 -> T=500, "
                                    "D=240, 5xBLSTM H=320, V=1000, L=100",
                        "global_batch": 32 * world, "parallelism": f"dp{world}",
@@ -638,6 +840,10 @@ def main():
                 tot_b, tot_s = sum(a["bytes"] for a in ar), sum(a["us"] for a in ar) * 1e-6
                 res["allreduce_bus_GBs"] = tot_b / tot_s / 1e9 * 2.0 * (world - 1) / world
                 res["xgmi_link_peak_GBs"] = XGMI_LINK_GBS
+            n1 = n1_reference()
+            if n1 is not None:       # weak scaling: N ranks each do the N = 1 work; efficiency = t(1) / t(N)
+                res["scaling_efficiency_vs"] = {"n1_ms_per_step": n1[0], "source": n1[1],
+                                                "efficiency": n1[0] / ms}
             if os.environ.get("ASR_BENCH_ONE_DEVICE"):
                 res["rehearsal"] = (f"{world} ranks share GPU 0 over {dist.get_backend()}: the N-rank code path "
                                     "(hooks, side-stream packing, collective, mean), NOT a throughput claim")
@@ -645,12 +851,23 @@ def main():
         if probes:
             res["roofline"] = dict(probes["blstm_bwd"])
             res["roofline_all"] = probes
+        if world == 1 and not force_dp:
+            n1_store(ms)
+        if world == 1 and not args.no_config4:
+            try:
+                res["config4_csj"] = config4_probe(dev)
+            except Exception as e:      # a side measurement must never cost the headline line
+                res["config4_csj"] = {"error": repr(e)[:300]}
         if world == 1 and not args.no_config5:
             try:
                 res["config5_conformer"] = config5_probe(dev)
             except Exception as e:      # a side measurement must never cost the headline line
                 res["config5_conformer"] = {"error": repr(e)[:300]}
         if world == 1 and not args.no_cpu_baseline:
+            try:
+                res["config1_speech_commands"] = config1_probe(dev)
+            except Exception as e:
+                res["config1_speech_commands"] = {"error": repr(e)[:300]}
             res["cpu_baseline"] = cpu_baseline(make_hp(encoder_dropout=0.0))
         print(json.dumps(res), flush=True)
     reducer.close()

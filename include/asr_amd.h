@@ -164,7 +164,7 @@ int asr_sgemm(const asr_gemm_desc *d, void *stream);
  *   1  bf16x3: every fp32 operand split into two bf16 (hi + lo), three products per term on the bf16 matrix
  *      pipe, fp32 accumulate -- ~16 mantissa bits per product, inside the fp32 parity bar (1e-4 / 1e-3);
  *   2  plain bf16 products (8 mantissa bits), fp32 accumulate: the opt-in reduced-precision path, with a
- *      looser, stated tolerance (tests/test_gpu_parity.py::test_bf16_mode_tolerance).
+ *      looser, stated tolerance (tests/test_gpu_parity.py::test_attmodel_gemm_precision_modes).
  * Returns the previous mode; a mode outside 0..2 only queries.  Start-up value: environment variable
  * ASR_GEMM_PRECISION = f32 | bf16x3 | bf16 (default bf16x3).  Shapes outside the fast path (unaligned
  * operands, K < 32) use mode 0 whatever the setting. */
@@ -206,8 +206,10 @@ int asr_scale(float *x, int64_t n, float s, void *stream);
  * already reads every step -- the reference ends the job on a NaN loss, train.py:66-68. */
 int asr_poison_if_flag(const void *flag_word, float *value, void *stream);
 /* A HIP stream with a hardware queue of its own at normal priority (created with a compute-unit
- * mask: bit i of cu_mask = compute unit i; NULL / 0 words = every CU), for the work that overlaps the
+ * mask: bit i of cu_mask = compute unit i; NULL / 0 words = every CU), for work that overlaps the
  * backward's critical path -- the reference leaves stream handling to DDP's reducer (train.py:141).
+ * Optional: asr_amd/streams.py uses it only under ASR_SIDE_STREAM_KIND=cumask; its default helper
+ * streams are plain normal-priority streams created before the process group (streams.prepare).
  * Destroy it with asr_stream_destroy once its work has completed. */
 int asr_stream_create(void **stream, const uint32_t *cu_mask, int n_words);
 int asr_stream_destroy(void *stream);
@@ -293,8 +295,14 @@ int asr_blstm_fwd_range(const float *W_hh, float *G, float *Cs, float *Hout,
  * floats (264.25 KiB, one copy per GPU the library runs on, held until the process ends); shapes
  * beyond it (B > 32, H > 512, H % 4 != 0) are rejected with ASR_ERR_ARG.  Every call on a GPU
  * shares that GPU's array: calls that overlap on one GPU (two streams) race.  Same results as
- * asr_blstm_fwd, bit for bit. */
+ * asr_blstm_fwd, bit for bit.  The stream must belong to the current device (checked).
+ * asr_blstm_fwd_noalloc_err_word(): device address (current device) of the sticky error word inside the
+ * static array -- the counterpart of word 1024 of a workspace: non-zero once a launch's in-kernel wait has
+ * timed out, after which that call's Hout / Cs are garbage although it returned ASR_OK (launches are
+ * asynchronous).  Pass it to asr_poison_if_flag on the same stream, or copy the 4 bytes back; the library
+ * never clears it.  NULL on failure (asr_last_error). */
 int64_t asr_blstm_fwd_noalloc_max_floats(void);
+const void *asr_blstm_fwd_noalloc_err_word(void);
 int asr_blstm_fwd_noalloc(const float *W_hh, float *G, float *Cs, float *Hout,
                           int64_t ho_t, int64_t ho_b, const int32_t *lengths,
                           int T, int B, int H, void *stream);
@@ -464,6 +472,11 @@ int asr_attdec_fwd(const asr_attdec_fwd_args *a, void *stream);
  * asr_attdec_err_offset: index (in floats) inside a->ws of a 4-byte word that is non-zero after the call iff an
  * in-launch wait timed out (outputs invalid) -- fold it into the loss with asr_poison_if_flag. */
 int asr_attdec_persist(int on);
+/* Which form the two calls take for a shape on the current device when every tensor is 16-byte aligned: bit 0 = the
+ * forward runs as one persistent launch, bit 1 = the backward does; 0 after asr_attdec_persist(0).  A caller whose
+ * batch is too large for one launch (B * ceil(T/64) > compute units: T = 800 at B = 32, the CSJ shape) can split it
+ * into parts that fit -- utterances are independent inside Models/decoder.py:52-60 -- as asr_amd/Models/decoder.py does. */
+int asr_attdec_plan(int B, int T, int E, int Hd, int L);
 /* diagnostics (tools/dec_stamps.py): device buffer for per-phase time stamps of the persistent launches, NULL = off */
 void asr_attdec_debug_stamps(void *buf);
 int64_t asr_attdec_err_offset(int B, int T, int E, int Hd, int L);

@@ -33,6 +33,25 @@ def test_gpus2_spawns_two_ranks_stubbed_step():
     assert res["allreduce_bytes_per_step"] > 0
 
 
+def test_gpus8_spawns_eight_ranks_stubbed_step():
+    """The launch the driver's 8-GPU node sees (`--gpus 8`), rehearsed with eight gloo ranks on the CPU: one line from
+    rank 0 with the fields the scaling run is read from (rccl_ranks, per_rank_ms, allreduce_bus_GBs) and
+    `scaling_efficiency_vs` against the N = 1 step time handed over in ASR_BENCH_N1_MS."""
+    r = _run({"ASR_BENCH_STUB": "1", "ASR_BENCH_N1_MS": "5.0", "OMP_NUM_THREADS": "1"},
+             "--gpus", "8", "--steps", "2", "--warmup", "1")
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    res = json.loads(lines[0])
+    assert res["n_gpus"] == 8 and res["rccl_ranks"] == 8 and res["gpus_arg"] == 8
+    assert len(res["per_rank_ms"]) == 8 and all(v > 0 for v in res["per_rank_ms"])
+    assert res["allreduce_bus_GBs"] > 0 and len(res["allreduce_buckets"]) == 3
+    assert res["mean_ok"] is True                       # mean of 1..8 = 4.5 on every parameter
+    eff = res["scaling_efficiency_vs"]
+    assert eff["n1_ms_per_step"] == 5.0 and eff["source"] == "ASR_BENCH_N1_MS"
+    assert abs(eff["efficiency"] - 5.0 / res["ms_per_step"]) < 1e-9
+
+
 def test_gpus2_without_gpus_refuses_loudly():
     """No stub, no rehearsal, fewer than N GPUs: the parent must say so and fail, not run one rank."""
     import torch

@@ -840,21 +840,43 @@ def test_timed_out_wait_poisons_the_loss():
     dev = _dev()
     hp = R.make_hp(lmfb_dim=6, frame_stacking=1, num_hidden_nodes=16, num_encoder_layer=1, encoder_dropout=0.0)
     enc = Encoder(hp).to(dev)
-    enc(torch.randn(3, 9, 6, device=dev), torch.tensor([9, 5, 2]))      # makes sure a workspace exists
+    xin, lens = torch.randn(3, 9, 6, device=dev), torch.tensor([9, 5, 2])
+    enc(xin, lens)      # makes sure a workspace exists
     assert persist._WS and not persist.error_flags()
     z = torch.randn(2, 3, 12, device=dev, requires_grad=True)
     tgt = torch.randint(0, 12, (2, 3), device=dev)
     tl = torch.tensor([3, 2], device=dev)
     clean = label_smoothing_loss(z, tgt, tl)
     assert bool(torch.isfinite(clean))
-    ws = next(w for (idx, _, _, _), w in persist._WS.items() if idx == dev.index)
+    ws = persist._WS[(dev.index, 3, 16, torch.cuda.current_stream(dev).cuda_stream)]      # this encoder's: B = 3, H = 16
     try:
         ws.view(torch.int32)[persist.ERR_WORD] = 1
         assert persist.error_flags()
+        # the loss looks at the workspaces used since the last loss: a launch that used this one (the only way the
+        # word gets set) puts it on that list; the launch's own set-up never clears the sticky word
+        enc(xin, lens)
+        assert persist.error_flags()
         assert bool(torch.isnan(label_smoothing_loss(z, tgt, tl)))
+        # ... and a backward launch folds it into its layer's bias gradients at once
+        enc.zero_grad(set_to_none=True)
+        enc(xin, lens).sum().backward()
+        assert bool(torch.isnan(enc.bi_lstm.bias_ih_l0.grad[0])) and bool(torch.isnan(enc.bi_lstm.bias_hh_l0.grad[0]))
+        # one NaN entry makes the global norm NaN: the fused clip + Adam then writes NaN everywhere, as stock
+        # clip_grad_norm_ + Adam do -- the job cannot train on past the failure
+        from asr_amd.optim import ClipAdam
+        import copy
+        enc2 = copy.deepcopy(enc)
+        for p2, p1 in zip(enc2.parameters(), enc.parameters()):
+            p2.grad = p1.grad.clone()
+        ClipAdam(enc2.parameters(), lr=1e-3).step(max_norm=5.0)
+        assert all(bool(torch.isnan(p2).all()) for p2 in enc2.parameters())
     finally:
         ws.view(torch.int32)[persist.ERR_WORD] = 0
+    enc(xin, lens)
     assert float(label_smoothing_loss(z, tgt, tl)) == float(clean)
+    enc.zero_grad(set_to_none=True)
+    enc(xin, lens).sum().backward()
+    assert all(bool(torch.isfinite(p.grad).all()) for p in enc.parameters())
 
 
 def test_second_backward_raises_clearly():
@@ -992,16 +1014,28 @@ def test_attmodel_gemm_precision_modes(mode, loss_tol, out_tol, grad_tol):
                                                 (32, 374, 128, 320, 1000, 7, "ragged"),      # config-5 decoder: E = 256
                                                 (32, 448, 320, 320, 1000, 5, "full"),        # no empty tile: X jobs on loaded tiles
                                                 (16, 512, 320, 320, 1000, 4, "full"),        # one batch tile, T a multiple of 64
+                                                (16, 800, 320, 320, 1000, 4, "full"),        # 13 tiles: 22 frames per thread in the context sum
+                                                (32, 800, 320, 320, 7000, 6, "ragged"),      # config-4 (CSJ) decoder: two parts of 16 utterances
+                                                (32, 800, 320, 320, 7000, 3, "ragged+side"),  # ... its weight gradients summed on the side stream
                                                 (18, 70, 8, 16, 9, 4, None), (3, 17, 4, 8, 7, 5, [17, 9, 4])])
 def test_decoder_persistent_loop_vs_per_step_launches(B, T, He, Hd, V, L, lens):
     """The one-launch decoder loop (in-launch hand-offs between workgroups) against the four-launches-per-step
     loop on the same inputs: outputs and every gradient (the backward consumes what the forward saved: S, C,
-    alpha, sproj, g, gates, Fc).  The two differ only in the order of the context sums."""
-    from asr_amd import _lib
-    from asr_amd.Models.decoder import Decoder
+    alpha, sproj, g, gates, Fc).  The two differ only in the order of the context sums.  Every shape here must TAKE
+    the one-launch form (asr_attdec_plan), the config-4 shape as two parts of 16 utterances (416 workgroups do not
+    fit 256 compute units; Decoder splits the batch, asr_amd/Models/decoder.py::batch_parts)."""
+    from asr_amd import _lib, streams
+    from asr_amd.Models.decoder import Decoder, batch_parts
     from oracle import ref_model as R
     lib = _lib.load()
     dev = _dev()
+    side = isinstance(lens, str) and lens.endswith("+side")
+    if side:
+        lens = lens[:-5]
+    parts = batch_parts(lib, B, T, 2 * He, Hd, L)
+    assert all(lib.asr_attdec_plan(b1 - b0, T, 2 * He, Hd, L) == 3 for b0, b1 in parts), parts
+    assert len(parts) == (2 if (B, T) == (32, 800) else 1), parts
+    assert sum(b1 - b0 for b0, b1 in parts) == B and parts[0][0] == 0 and parts[-1][1] == B
     hp = R.make_hp(num_hidden_nodes_encoder=He, num_hidden_nodes_decoder=Hd, num_classes=V)
     torch.manual_seed(T + Hd)
     dec = Decoder(hp).to(dev).train()
@@ -1017,10 +1051,11 @@ def test_decoder_persistent_loop_vs_per_step_launches(B, T, He, Hd, V, L, lens):
     tgt = torch.randint(0, V, (B, L)).to(dev)
     w = torch.randn(B, L, V).to(dev)
     res = []
-    was = lib.asr_attdec_persist(-1)
+    was, side_was = lib.asr_attdec_persist(-1), streams.ENABLED
     try:
         for on in (0, 1):
             lib.asr_attdec_persist(on)
+            streams.enable(side and on == 1)
             dec.zero_grad(set_to_none=True)
             hd = h.to(dev).requires_grad_(True)
             y = dec(hd, lengths, tgt)
@@ -1029,6 +1064,7 @@ def test_decoder_persistent_loop_vs_per_step_launches(B, T, He, Hd, V, L, lens):
             res.append((y.detach().clone(), hd.grad.clone(), {k: p.grad.clone() for k, p in dec.named_parameters()}))
     finally:
         lib.asr_attdec_persist(was)
+        streams.enable(side_was)
     (y0, dh0, g0), (y1, dh1, g1) = res
     assert bool(torch.isfinite(y1).all())
     assert rel_err(y1.cpu(), y0.cpu()) < 1e-5
