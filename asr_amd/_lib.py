@@ -105,12 +105,14 @@ SYMBOLS = {
     "asr_blstm_ws_floats": (c_i64, [C.c_int, C.c_int]),
     "asr_blstm_precision": (C.c_int, [C.c_int]),
     "asr_blstm_xcd_groups": (C.c_int, [C.c_int]),
+    "asr_blstm_prefetch": (C.c_int, [C.c_int]),
     "asr_blstm_bwd_needs_transposed": (C.c_int, [C.c_int, C.c_int, C.c_int, c_i64, c_i64, C.c_int]),
     "asr_blstm_fwd": (C.c_int, [c_f, c_f, c_f, c_f, c_i64, c_i64, c_f, C.c_int, C.c_int, C.c_int, c_f, c_f]),
     "asr_blstm_fwd_noalloc_max_floats": (c_i64, []),
     "asr_blstm_fwd_noalloc_err_word": (C.c_void_p, []),
     "asr_blstm_fwd_noalloc": (C.c_int, [c_f, c_f, c_f, c_f, c_i64, c_i64, c_f, C.c_int, C.c_int, C.c_int, c_f]),
     "asr_poison_if_flag": (C.c_int, [c_f, c_f, c_f]),
+    "asr_debug_occupy": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, c_f]),
     "asr_stream_create": (C.c_int, [C.POINTER(C.c_void_p), c_f, C.c_int]),
     "asr_stream_destroy": (C.c_int, [c_f]),
     "asr_blstm_bwd": (C.c_int, [c_f, c_f, c_f, c_f, c_f, c_i64, c_i64, c_f, c_f, C.c_int, C.c_int, C.c_int,

@@ -754,7 +754,7 @@ static bool al16(const void *p) { return (((uintptr_t)p) & 15) == 0; }
 #define PD_HF_MAX 22       // ... of the forward instantiation for long utterances (T = 800: 39 frame groups x 21)
 #define PD_AL (32 * PD_MTP)   // attention units the LDS tables are padded to (zeros past A)
 #define PD_KF 5            // float4 per lane of a job's K slot: K <= 32 slots x 20 = 640
-#define PD_SPIN_LIMIT (1 << 20)
+// in-launch waits are bounded by wall time: asr_wait_expired (common.cuh), 4 s on the 100 MHz counter
 #define PD_OOB 0x7ffffff0
 typedef unsigned int pd_u32x4 __attribute__((ext_vector_type(4)));
 
@@ -801,12 +801,20 @@ template <int NF>
 __device__ __forceinline__ void pd_gather(float4 (&v)[NF], __amdgpu_buffer_rsrc_t r, const int (&off)[NF], unsigned want,
                                           int probe, int *s_abort, unsigned *err) {
     int spins = 0;
+    unsigned long long t0 = 0;
+    bool late = false;
     for (;; ++spins) {
         const float4 t = pd_ld4_sc1(r, probe);
-        if (__all(pd_tags_ok(t, want) | (probe == PD_OOB)) || spins >= PD_SPIN_LIMIT) break;
+        if (__all(pd_tags_ok(t, want) | (probe == PD_OOB))) break;
+        if (asr_wait_expired(spins, t0)) {
+            late = true;
+            break;
+        }
         __builtin_amdgcn_s_sleep(1);
     }
-    for (;; ++spins) {
+    // the full gather: normally one pass; a probe that ran out of time gives it one attempt
+    unsigned long long t1 = 0;
+    for (spins = 0;; ++spins) {
 #pragma unroll
         for (int f = 0; f < NF; ++f) v[f] = pd_ld4_sc1(r, off[f]);
         __builtin_amdgcn_sched_barrier(0);
@@ -814,7 +822,7 @@ __device__ __forceinline__ void pd_gather(float4 (&v)[NF], __amdgpu_buffer_rsrc_
 #pragma unroll
         for (int f = 0; f < NF; ++f) ok = ok & (pd_tags_ok(v[f], want) | (off[f] == PD_OOB));
         if (__all(ok)) return;
-        if (spins >= PD_SPIN_LIMIT) {
+        if (late || asr_wait_expired(spins, t1)) {
             if ((threadIdx.x & 63) == 0) {
                 *s_abort = 1;
                 __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

@@ -185,7 +185,7 @@ static int blstm_bwd_steps(const float *W_hhT, float *G, const float *Cs, const 
 // budget sets *err and makes the workgroup leave; the others then time out the
 // same way, so the grid always drains.
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-#define SPIN_LIMIT (1 << 21)
+// in-launch waits are bounded by wall time: asr_wait_expired (common.cuh), 4 s on the 100 MHz counter
 #define BLSTM_FLAG_WORDS_ 1024   // = BLSTM_FLAG_WORDS (defined with the host dispatch)
 #define BLSTM_PACE_START 8     // initial wait before a step's first exchange gather, units of s_sleep 2
 #define BLSTM_PACE_MAX 40
@@ -230,10 +230,88 @@ __device__ __forceinline__ f32x4 bl_mfma3(const u32x4 &ah, const u32x4 &al, cons
     return acc;
 }
 
+// ------------------------------------------------- saved-activation prefetch --
+// In a training step the backward recurrence of a layer finds its saved activations COLD: the layer's gates (164 MB at
+// the config-2 size), cell states and upstream gradient were written a whole forward + decoder pass ago, and the
+// side stream's weight-gradient GEMMs stream hundreds of MB through the 256 MiB Infinity Cache meanwhile.  Alone on a
+// warm working set a launch takes 815-840 us, after a 1 GiB fill 970, in the step 1030; READING the tensors once
+// after the fill brings 970 back to 831 (tools/lstm_cold.py, LSTM_TOUCH=1) -- a line fetched by anybody sits in the
+// memory-side cache for everybody.  The XCD-grouped grid has workgroups to spare (labels 2 NBT .. 7 used to leave
+// at once); they now walk the time steps AHEAD of the recurrence and touch one dword of every 128-byte line the step
+// will load -- G, Cs, dHout rows of the frames inside their sequences -- staying `dist` steps ahead of the slowest
+// group's published progress: far enough to cover an HBM round trip several times over, near enough that the
+// GEMMs' traffic does not push the lines out again before use.  Nothing depends on it: the loads are range-checked
+// buffer loads whose results are dropped, a prefetcher that loses sight of the progress words (4 s) just leaves.
+// Progress words: ws word BLSTM_PROG_WORD + group = (launch stamp & 0xffff) << 16 | step, written by thread 0 of
+// the group's workgroup 0 every step (a branch-free buffer store; every other lane's offset is out of range);
+// 0xffff = the group has left its loop.  A word with another launch's stamp counts as "not started".
+#define BLSTM_PROG_WORD 1032      // 8 words: backward groups (words 1025..2047 of the workspace are otherwise unused)
+#define BLSTM_PROG_WORD_FWD 1040  // 8 words: forward groups
+__device__ __noinline__ void blstm_prefetch_steps(const float *G, int64_t g_bytes, int g_row, const float *Cs, int64_t c_bytes,
+                                                  const float *X, int64_t x_bytes, int64_t x_t, int64_t x_b,
+                                                  const int32_t *lengths, int T, int B, int H, int s0, int s1,
+                                                  bool dir0_descends, const unsigned *prog, int ngroups, unsigned stamp16,
+                                                  int dist, int pw, int npw) {
+    // G rows are g_row floats per (frame, row, direction); Cs / X (= dHout) may be nullptr: the forward reads only G.
+    // Unit of work of a WAVE: one (step, direction, quarter of the batch rows) -- all its touches are issued before
+    // the first is waited for, so a unit costs one memory round trip and `dist` can stay small.
+    const int lane = threadIdx.x & 63;
+    __amdgpu_buffer_rsrc_t rG = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(G), 0, (int)g_bytes, 0x00020000);
+    __amdgpu_buffer_rsrc_t rC = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(Cs ? Cs : G), 0, (int)(Cs ? c_bytes : 0), 0x00020000);
+    __amdgpu_buffer_rsrc_t rX = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(X ? X : G), 0, (int)(X ? x_bytes : 0), 0x00020000);
+    constexpr int NPART = 8;                               // 2 directions x 4 row chunks
+    const int RB = (B + 3) / 4;
+    const int nlg = (g_row * 4 + 127) / 128 + 1, nlc = (H * 4 + 127) / 128 + 1;   // touches per row segment: every 128 B + its last dword
+    const int nG = RB * nlg, nC = Cs ? RB * nlc : 0, nX = X ? RB * nlc : 0, ntot = nG + nC + nX;
+    const int nunits = (s1 - s0) * NPART;
+    for (int u = pw; u < nunits; u += npw) {
+        const int s = s0 + u / NPART, part = u % NPART, d = part & 1, rb0 = (part >> 1) * RB;
+        const int t = (d == 0) == dir0_descends ? T - 1 - s : s;
+        unsigned long long t0 = 0;
+        for (int spins = 0;; ++spins) {      // stay within `dist` steps of the slowest group
+            int p = 0x7fffffff;
+            for (int g = 0; g < ngroups; ++g) {
+                const unsigned w = __hip_atomic_load(prog + g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const int ps = (w >> 16) != stamp16 ? s0 : ((w & 0xffffu) == 0xffffu ? 0x7fffffff : (int)(w & 0xffffu));
+                p = min(p, ps);
+            }
+            if (p == 0x7fffffff) return;     // every group has left its loop
+            if (s <= p + dist) break;
+            if (asr_wait_expired(spins, t0)) return;
+            __builtin_amdgcn_s_sleep(32);
+        }
+        for (int base = 0; base < ntot; base += 64 * 16) {
+            unsigned v[16];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                int idx = base + 64 * k + lane;
+                const bool in = idx < ntot;
+                // which tensor, row of the chunk, touch within the row segment
+                const int which = idx < nG ? 0 : (idx < nG + nC ? 1 : 2);
+                idx -= which == 0 ? 0 : (which == 1 ? nG : nG + nC);
+                const int nl = which == 0 ? nlg : nlc;
+                const int r = idx / nl, l = idx - r * nl, b = rb0 + r;
+                const bool ok = in && b < B && t < lengths[b < B ? b : 0];
+                const int seg = (which == 0 ? g_row : H) * 4;
+                const int64_t row0 = which == 0 ? ((((int64_t)t * B + b) * 2 + d) * g_row) * 4
+                                   : (which == 1 ? ((((int64_t)t * B + b) * 2 + d) * H) * 4
+                                                 : (t * x_t + b * x_b + (int64_t)d * H) * 4);
+                const int off = ok ? (int)(row0 + min(l * 128, seg - 4)) : OOB_OFF;
+                v[k] = which == 0 ? __builtin_amdgcn_raw_buffer_load_b32(rG, off, 0, 0)
+                     : (which == 1 ? __builtin_amdgcn_raw_buffer_load_b32(rC, off, 0, 0)
+                                   : __builtin_amdgcn_raw_buffer_load_b32(rX, off, 0, 0));
+            }
+#pragma unroll
+            for (int k = 0; k < 16; ++k) asm volatile("" ::"v"(v[k]));
+        }
+    }
+}
+
 // wave-wide: wait until flags[0..n) >= want (n <= 128).  Returns false on timeout.
 __device__ __forceinline__ bool poll_flags(unsigned *flags, int n, unsigned want) {
     const int lane = threadIdx.x & 63;
-    for (int spins = 0; spins < SPIN_LIMIT; ++spins) {
+    unsigned long long t0 = 0;
+    for (int spins = 0; !asr_wait_expired(spins, t0); ++spins) {
         unsigned v0 = lane < n ? __hip_atomic_load(flags + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
                                : 0xffffffffu;
         unsigned v1 = lane + 64 < n ? __hip_atomic_load(flags + lane + 64, __ATOMIC_RELAXED,
@@ -261,8 +339,10 @@ __global__ __launch_bounds__(256) void blstm_fwd_persist_kernel(
     const float *__restrict__ W_hh, float *__restrict__ G, float *__restrict__ Cs,
     float *__restrict__ Hout, int64_t ho_t, int64_t ho_b, int64_t hout_bytes,
     const int32_t *__restrict__ lengths, int T, int B, int H, int s0, int s1, float *hx, unsigned *flags,
-    unsigned *err, int dbg_arg, int tagmode_arg, int xcd_nbt = 0, unsigned xcd_epoch = 0) {
+    unsigned *err, int dbg_arg, int tagmode_arg, int xcd_nbt_arg = 0, unsigned xcd_epoch = 0) {
     const int dbg = PROD ? 0 : dbg_arg, tagmode = PROD ? 1 : tagmode_arg;
+    const int pf_dist = PROD ? (xcd_nbt_arg >> 8) : 0;      // prefetch distance in steps (0: off), see blstm_prefetch_steps
+    const int xcd_nbt = xcd_nbt_arg & 0xff;
     static_assert(MT * NT == 2 || (MT == 1 && NT == 1), "128 (64) owner threads");
     constexpr int UN = 4 * NT;                               // hidden units per workgroup
     __shared__ float red[2][4][MT][NT][16][17];
@@ -274,7 +354,15 @@ __global__ __launch_bounds__(256) void blstm_fwd_persist_kernel(
     int jt = blockIdx.x, d = blockIdx.y, bt = blockIdx.z, NJ = gridDim.x, NBT = gridDim.z;
     if (xcd_nbt > 0) {
         const int grp = blockIdx.x & 7;
-        if (grp >= 2 * xcd_nbt) return;
+        if (grp >= 2 * xcd_nbt) {       // spare workgroups: touch the input-projection gates ahead of the recurrence
+            if (pf_dist > 0)
+                blstm_prefetch_steps(G, (int64_t)T * B * 8 * H * 4, 4 * H, nullptr, 0, nullptr, 0, 0, 0, lengths, T, B, H,
+                                     s0 == 0 ? 1 : s0, s1, false, flags + BLSTM_PROG_WORD_FWD, 2 * xcd_nbt,
+                                     xcd_epoch & 0xffffu, pf_dist,
+                                     ((grp - 2 * xcd_nbt) * (int)(gridDim.x >> 3) + (int)(blockIdx.x >> 3)) * 4 + (int)(threadIdx.x >> 6),
+                                     (8 - 2 * xcd_nbt) * (int)(gridDim.x >> 3) * 4);
+            return;
+        }
         jt = blockIdx.x >> 3; d = grp & 1; bt = grp >> 1; NJ = gridDim.x >> 3; NBT = xcd_nbt;
     }
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -379,6 +467,10 @@ __global__ __launch_bounds__(256) void blstm_fwd_persist_kernel(
     __amdgpu_buffer_rsrc_t rC = __builtin_amdgcn_make_buffer_rsrc(Cs, 0, (int)((int64_t)T * B * 2 * H * 4), 0x00020000);
     __amdgpu_buffer_rsrc_t rH = __builtin_amdgcn_make_buffer_rsrc(Hout, 0, (int)hout_bytes, 0x00020000);
     const int gstep = valid ? H * 4 : 0;
+    // progress word of this (direction, batch tile) group, for the prefetching workgroups (blstm_prefetch_steps)
+    __amdgpu_buffer_rsrc_t rP = __builtin_amdgcn_make_buffer_rsrc(flags + BLSTM_PROG_WORD_FWD, 0, 8 * 4, 0x00020000);
+    const int prog_off = (xcd_nbt > 0 && pf_dist > 0 && jt == 0 && tid == 0) ? (d * NBT + bt) * 4 : OOB_OFF;
+    const unsigned prog_stamp = (xcd_epoch & 0xffffu) << 16;
     // Shadow lanes: the threads right behind the owners (no cell of their own) load the NEXT step's input-projection
     // gates of the owner MT*NT*64 places before them and drop the values.  In the training step G is cold (164 MB per
     // layer); the touch brings the lines into this CU's L1 / the XCD's L2 a step before the owner needs them.
@@ -514,6 +606,8 @@ __global__ __launch_bounds__(256) void blstm_fwd_persist_kernel(
                 pre[g] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rG, goff + g * gst, 0, 0));
         }
         store_saved();
+        if (PROD)   // progress word for the prefetchers: one lane of the group in range, write-through
+            __builtin_amdgcn_raw_buffer_store_b32(prog_stamp | (unsigned)s, rP, prog_off, 0, 16);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int m = 0; m < MT; ++m)
@@ -529,8 +623,9 @@ __global__ __launch_bounds__(256) void blstm_fwd_persist_kernel(
                     calm = 0;
                 }
             }
+            unsigned long long t0 = 0;
             for (int spins = 0; !__all(ok); ++spins) {   // wave-uniform
-                if (spins >= SPIN_LIMIT) {
+                if (asr_wait_expired(spins, t0)) {
                     if (lane == 0) {
                         s_abort = 1;
                         __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -596,6 +691,7 @@ __global__ __launch_bounds__(256) void blstm_fwd_persist_kernel(
         cell(s, t, growb, pre, true);
     }
     store_saved();   // the last processed step's saved activations
+    if (PROD) __builtin_amdgcn_raw_buffer_store_b32(prog_stamp | 0xffffu, rP, prog_off, 0, 16);   // this group is done
 }
 
 // grid (NJT = H/16, 2, NBT = ceil(B/16)), block 256: workgroup = 16 hidden units x 16 batch
@@ -733,7 +829,7 @@ __global__ __launch_bounds__(256) void blstm_bwd_rs_kernel(
     const float *__restrict__ W_hh, float *__restrict__ G, const float *__restrict__ Cs,
     const float *__restrict__ dHout, int64_t dho_t, int64_t dho_b, const int32_t *__restrict__ lengths,
     int64_t dh_bytes, int T, int B, int H, int s0, int s1, float *__restrict__ dc_ws, float *xP, unsigned *flags,
-    unsigned *err, int dbg_arg, int tagmode_arg, int xcd_nbt = 0, unsigned xcd_epoch = 0) {
+    unsigned *err, int dbg_arg, int tagmode_arg, int xcd_nbt_arg = 0, unsigned xcd_epoch = 0) {
     const int dbg = PROD ? 0 : dbg_arg, tagmode = PROD ? 1 : tagmode_arg;
     constexpr int KL = 4 * UW, KS = KL / 4, DSTR = KL + 4;
     constexpr int NI = 16 * UW / 4;     // 16-byte items per source workgroup (16 rows x UW/4)
@@ -744,9 +840,19 @@ __global__ __launch_bounds__(256) void blstm_bwd_rs_kernel(
     __shared__ int s_abort, s_local;
     // classic grid (NJT, 2, NBT), or the XCD-grouped one of the forward kernel (8 * NJT workgroups, label = id & 7)
     int jt = blockIdx.x, d = blockIdx.y, bt = blockIdx.z, NJT = gridDim.x, NBT = gridDim.z;
+    const int pf_dist = PROD ? (xcd_nbt_arg >> 8) : 0;      // prefetch distance in steps (0: off), see blstm_prefetch_steps
+    const int xcd_nbt = xcd_nbt_arg & 0xff;
     if (xcd_nbt > 0) {
         const int grp = blockIdx.x & 7;
-        if (grp >= 2 * xcd_nbt) return;
+        if (grp >= 2 * xcd_nbt) {
+            if (pf_dist > 0)
+                blstm_prefetch_steps(G, (int64_t)T * B * 8 * H * 4, 4 * H, Cs, (int64_t)T * B * 2 * H * 4, dHout, dh_bytes,
+                                     dho_t, dho_b, lengths, T, B, H, s0 == 0 ? 1 : s0, s1, true, flags + BLSTM_PROG_WORD,
+                                     2 * xcd_nbt, xcd_epoch & 0xffffu, pf_dist,
+                                     ((grp - 2 * xcd_nbt) * (int)(gridDim.x >> 3) + (int)(blockIdx.x >> 3)) * 4 + (int)(threadIdx.x >> 6),
+                                     (8 - 2 * xcd_nbt) * (int)(gridDim.x >> 3) * 4);
+            return;
+        }
         jt = blockIdx.x >> 3; d = grp & 1; bt = grp >> 1; NJT = gridDim.x >> 3; NBT = xcd_nbt;
     }
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -832,6 +938,10 @@ __global__ __launch_bounds__(256) void blstm_bwd_rs_kernel(
                                                                   0x00020000);
     float sv[4] = {0.f, 0.f, 0.f, 0.f};   // dG of the previous step, stored one step late
     int sv_g = OOB_OFF;
+    // progress word of this (direction, batch tile) group, for the prefetching workgroups (blstm_prefetch_steps)
+    __amdgpu_buffer_rsrc_t rP = __builtin_amdgcn_make_buffer_rsrc(flags + BLSTM_PROG_WORD, 0, 8 * 4, 0x00020000);
+    const int prog_off = (xcd_nbt > 0 && pf_dist > 0 && jt == 0 && tid == 0) ? (d * NBT + bt) * 4 : OOB_OFF;
+    const unsigned prog_stamp = (xcd_epoch & 0xffffu) << 16;
     // the set-up loads are consumed here: a load pending at the loop entry would cost a
     // conservative queue drain in every iteration
 #pragma unroll
@@ -1024,6 +1134,8 @@ __global__ __launch_bounds__(256) void blstm_bwd_rs_kernel(
             a_next2 = load_act(tn, actn, actn ? gate_offset(tn) : OOB_OFF);
         }
         store_saved();
+        if (PROD)   // progress word for the prefetchers: one lane of the group in range, write-through
+            __builtin_amdgcn_raw_buffer_store_b32(prog_stamp | (unsigned)s, rP, prog_off, 0, 16);
         __builtin_amdgcn_sched_barrier(0);
         bool ok = true;
 #pragma unroll
@@ -1038,8 +1150,9 @@ __global__ __launch_bounds__(256) void blstm_bwd_rs_kernel(
                     calm = 0;
                 }
             }
+            unsigned long long t0 = 0;
             for (int spins = 0; !__all(ok); ++spins) {   // wave-uniform
-                if (spins >= SPIN_LIMIT) {
+                if (asr_wait_expired(spins, t0)) {
                     if (lane == 0) {
                         s_abort = 1;
                         __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1063,10 +1176,11 @@ __global__ __launch_bounds__(256) void blstm_bwd_rs_kernel(
         for (int c = 0; c < CH; ++c) { sum.x += v[c].x; sum.y += v[c].y; sum.z += v[c].z; sum.w += v[c].w; }
         for (int w0 = grp + CH * NG; w0 < NJT; w0 += NG) {   // rare: more than CH*NG sources
             float4 x = zero4();
+            unsigned long long t1 = 0;
             for (int spins = 0;; ++spins) {
                 x = ld4_sc1(rsrc, off0 + (int)((int64_t)w0 * MTILES * 256 * 4));
                 if (!tagmode || (dbg & 1) || __all(tags_ok(x, want))) break;
-                if (spins >= SPIN_LIMIT) {
+                if (asr_wait_expired(spins, t1)) {
                     if (lane == 0) {
                         s_abort = 1;
                         __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1094,6 +1208,7 @@ __global__ __launch_bounds__(256) void blstm_bwd_rs_kernel(
         cell(s, act, growb, a, dh);
     }
     store_saved();   // the last processed step's dG
+    if (PROD) __builtin_amdgcn_raw_buffer_store_b32(prog_stamp | 0xffffu, rP, prog_off, 0, 16);   // this group is done
     if (s1 < T && valid) dc_ws[((int64_t)d * B + b) * H + j] = dcarry;   // picked up by the next launch
 }
 
@@ -1195,6 +1310,32 @@ extern "C" int asr_blstm_xcd_groups(int mode) {
     if (mode == 0 || mode == 1) g_blstm_xcd = mode;
     return old;
 }
+// Steps the prefetching workgroups of the XCD-grouped grids stay ahead of the recurrence (blstm_prefetch_steps);
+// ASR_BLSTM_PREFETCH=0 switches them off, asr_blstm_prefetch(n) at run time (returns the previous value; n < 0 queries).
+static int g_blstm_pf = -1;
+static int blstm_prefetch_dist() {
+    if (g_blstm_pf < 0) {
+        const char *e = getenv("ASR_BLSTM_PREFETCH");
+        g_blstm_pf = e ? atoi(e) : 12;
+        if (g_blstm_pf < 0) g_blstm_pf = 0;
+        if (g_blstm_pf > 255) g_blstm_pf = 255;
+    }
+    return g_blstm_pf;
+}
+static int blstm_prefetch_dist_fwd() {      // timing experiments: ASR_BLSTM_PREFETCH_FWD overrides the distance for the forward kernel
+    static int v = -2;
+    if (v == -2) {
+        const char *e = getenv("ASR_BLSTM_PREFETCH_FWD");
+        v = e ? atoi(e) : -1;
+        if (v > 255) v = 255;
+    }
+    return v >= 0 ? v : blstm_prefetch_dist();
+}
+extern "C" int asr_blstm_prefetch(int dist) {
+    const int old = blstm_prefetch_dist();
+    if (dist >= 0) g_blstm_pf = dist > 255 ? 255 : dist;
+    return old;
+}
 // stamp of a launch's XCD reports (24 bits, never 0): words left by an earlier launch do not count
 static unsigned blstm_xcd_epoch() {
     static unsigned epoch = 0;
@@ -1277,7 +1418,8 @@ extern "C" int asr_blstm_fwd_range(const float *W_hh, float *G, float *Cs, float
     } else if (bf && g_fwd_form == 0 && blstm_xcd_groups() && H / 8 <= 64) {
         // one (direction, batch tile) group of H/8 workgroups per XCD label (8 hidden units per workgroup)
         ok = launch_fwd_persist_bf<2>(cdiv(H / 32, 4), dim3(8 * (H / 8), 1, 1), st, W_hh, G, Cs, Hout, ho_t, ho_b, lengths,
-                                      T, B, H, s0, s1, hx, flags, err, MT, blstm_xcd_epoch());
+                                      T, B, H, s0, s1, hx, flags, err,
+                                      (2 * MT < 8 && T < 0xffff) ? (MT | (blstm_prefetch_dist_fwd() << 8)) : MT, blstm_xcd_epoch());
     } else if (bf && g_fwd_form == 0) {
         ok = launch_fwd_persist_bf<2>(cdiv(H / 32, 4), dim3(H / 8, 2, 2), st, W_hh, G, Cs, Hout, ho_t, ho_b, lengths, T,
                                       B, H, s0, s1, hx, flags, err);
@@ -1357,6 +1499,8 @@ extern "C" int asr_blstm_bwd_range(const float *W_hh, const float *W_hhT, float 
                 xcd_nbt = NBT;
                 xcd_epoch = blstm_xcd_epoch();
             }
+            // idle XCD labels prefetch the saved activations (blstm_prefetch_steps): product instantiation only
+            const int xcd_pf = (xcd_nbt > 0 && 2 * NBT < 8 && T < 0xffff) ? (xcd_nbt | (blstm_prefetch_dist() << 8)) : xcd_nbt;
             float *xP = ws + BLSTM_HX_OFF;
             bool launched = true;
             if (s0 == 0) {
@@ -1369,7 +1513,7 @@ extern "C" int asr_blstm_bwd_range(const float *W_hh, const float *W_hhT, float 
         if (bfb && g_dbg == 0 && g_tagmode == 1)                                                             \
             hipLaunchKernelGGL((blstm_bwd_rs_kernel<U, N, true, true>), g2, dim3(256), 0, st, W_hh, G, Cs,   \
                                dHout, dho_t, dho_b, lengths, dh_bytes, T, B, H, s0, s1, dc_ws, xP, flags,    \
-                               err, 0, 1, xcd_nbt, xcd_epoch);                                               \
+                               err, 0, 1, xcd_pf, xcd_epoch);                                                \
         else if (bfb)                                                                                        \
             hipLaunchKernelGGL((blstm_bwd_rs_kernel<U, N, true>), g2, dim3(256), 0, st, W_hh, G, Cs, dHout,  \
                                dho_t, dho_b, lengths, dh_bytes, T, B, H, s0, s1, dc_ws, xP, flags, err,      \

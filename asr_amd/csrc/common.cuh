@@ -136,5 +136,23 @@ __host__ __device__ __forceinline__ int64_t rowoff2(int64_t i, int d, int64_t s0
 
 static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 
+// Bound of every in-launch wait (a wave polling for data another workgroup of the same launch publishes): WALL TIME
+// on the constant-rate counter s_memrealtime reads (100 MHz on gfx950), not an iteration count.  An iteration
+// count measures nothing when the poll's own latency moves (a loaded fabric, a slow clock); what a bound has to
+// tell apart is "the producer is late" -- it is not resident yet because another kernel (an RCCL channel) still
+// holds its compute unit: milliseconds at most -- from "the producer will never come".  4 s is far beyond the first
+// and still ends a launch that cannot make progress.  `spins` counts the caller's polls; the counter is read once
+// per 256 of them (first at poll 255, which starts the clock), so the fast path pays nothing.
+#define ASR_WAIT_LIMIT_TICKS 400000000ull
+__device__ __forceinline__ bool asr_wait_expired(int spins, unsigned long long &t0) {
+    if ((spins & 255) != 255) return false;
+    const unsigned long long now = __builtin_amdgcn_s_memrealtime();
+    if (spins == 255) {
+        t0 = now;
+        return false;
+    }
+    return now - t0 > ASR_WAIT_LIMIT_TICKS;
+}
+
 __device__ __forceinline__ float4 ld4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
 __device__ __forceinline__ float4 zero4() { return make_float4(0.f, 0.f, 0.f, 0.f); }

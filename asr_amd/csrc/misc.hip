@@ -453,3 +453,33 @@ extern "C" int asr_stream_destroy(void *stream) {
     ASR_CHECK_HIP(hipStreamDestroy((hipStream_t)stream));
     return ASR_OK;
 }
+
+// ---------------------------------------------------------------------------
+// A stand-in for a collective's kernel, for tests and timing experiments only (tests/test_gpu_parity.py::
+// test_step_under_competing_kernels; never on the product path): n_wg workgroups of `threads` lanes that each hold
+// lds_bytes of LDS and a compute unit's wave slots for `usec` microseconds of wall time (the 100 MHz counter), doing
+// nothing.  RCCL's kernels look like this to the rest of the GPU: one workgroup per channel, resident for the length
+// of the collective, on whichever compute units the dispatcher picks.  The persistent kernels of this library need
+// all their workgroups resident at once; this lets a test check that they only WAIT while such a kernel is in the way.
+__global__ void occupy_kernel(int usec, int lds_floats, float *sink) {
+    extern __shared__ float occ_lds[];
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    float acc = 0.f;
+    for (int i = threadIdx.x; i < lds_floats; i += blockDim.x) occ_lds[i] = (float)i;
+    __syncthreads();
+    while (__builtin_amdgcn_s_memrealtime() - t0 < (unsigned long long)usec * 100ull) {
+        if (lds_floats > 0) acc += occ_lds[(threadIdx.x * 7) % lds_floats];
+        __builtin_amdgcn_s_sleep(8);
+    }
+    if (sink != nullptr && acc == -1.0f) sink[0] = acc;     // keeps the LDS reads alive; never true
+}
+
+extern "C" int asr_debug_occupy(int n_wg, int threads, int lds_bytes, int usec, void *stream) {
+    ASR_CHECK_ARG(n_wg > 0 && n_wg <= 4096 && threads >= 64 && threads <= 1024 && threads % 64 == 0 && lds_bytes >= 0 &&
+                      lds_bytes <= 64 * 1024 && usec >= 0 && usec <= 100000,
+                  "debug_occupy: bad argument (n_wg %d, threads %d, lds %d B, %d us)", n_wg, threads, lds_bytes, usec);
+    hipLaunchKernelGGL(occupy_kernel, dim3(n_wg), dim3(threads), (size_t)lds_bytes, (hipStream_t)stream, usec,
+                       lds_bytes / 4, (float *)nullptr);
+    ASR_CHECK_LAUNCH("occupy_kernel");
+    return ASR_OK;
+}

@@ -213,6 +213,11 @@ int asr_poison_if_flag(const void *flag_word, float *value, void *stream);
  * Destroy it with asr_stream_destroy once its work has completed. */
 int asr_stream_create(void **stream, const uint32_t *cu_mask, int n_words);
 int asr_stream_destroy(void *stream);
+/* Tests and timing experiments only (no counterpart in the reference, never on the product path): n_wg workgroups
+ * of `threads` lanes that hold lds_bytes (<= 64 KiB) of LDS each and do nothing for usec (<= 100000) microseconds of
+ * wall time -- what a collective's kernel (one resident workgroup per RCCL channel) looks like to the kernels that
+ * share the GPU with it.  tests/test_gpu_parity.py::test_step_under_competing_kernels runs a training step under it. */
+int asr_debug_occupy(int n_wg, int threads, int lds_bytes, int usec, void *stream);
 /* out[r] = argmax_c x[r*ld + c], first maximum (the frame-wise labels of CTCModel.decode,
  * Models/CTCModel.py:33: decoder_output[b].argmax(dim=1)) */
 int asr_argmax_rows(const float *x, int64_t rows, int cols, int64_t ld, int64_t *out, void *stream);
@@ -277,6 +282,11 @@ int asr_blstm_precision(int mode);
  * three-dimensional grid, write-through stores only.  Bit-identical results.  Returns the previous setting; other
  * values only query.  Start-up value: environment variable ASR_BLSTM_XCD = 0 | 1. */
 int asr_blstm_xcd_groups(int mode);
+/* With the XCD-grouped grid, the workgroups of the unused XCD labels touch the saved activations (gates, cell states,
+ * upstream gradient) `dist` time steps ahead of the recurrence, so that its own loads find them in the memory-side
+ * cache instead of HBM (no counterpart in the reference; results are unaffected).  dist = 0 switches it off; returns
+ * the previous value, a negative dist only queries.  Start-up value: environment variable ASR_BLSTM_PREFETCH (12). */
+int asr_blstm_prefetch(int dist);
 int asr_blstm_fwd(const float *W_hh, float *G, float *Cs, float *Hout,
                   int64_t ho_t, int64_t ho_b, const int32_t *lengths,
                   int T, int B, int H, float *ws, void *stream);

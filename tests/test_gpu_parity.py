@@ -879,6 +879,72 @@ def test_timed_out_wait_poisons_the_loss():
     assert all(bool(torch.isfinite(p.grad).all()) for p in enc.parameters())
 
 
+@pytest.mark.parametrize("n_wg,threads,lds,usec", [(32, 256, 16384, 250), (64, 512, 32768, 400), (256, 256, 8192, 150)])
+def test_step_under_competing_kernels(n_wg, threads, lds, usec):
+    """One training step at the config-2 size while ANOTHER stream keeps launching kernels that sit on compute units
+    and do nothing (asr_debug_occupy: a stand-in for RCCL's channel workgroups, which stay resident for the length of
+    a collective): the persistent kernels need all their workgroups resident at once, so while such a kernel is in
+    the way some of them start late and the others wait for them -- in-launch waits are bounded by wall time (4 s),
+    far beyond any collective, so nothing may time out: no error word, finite loss, and the gradients of the quiet
+    run (split-K float atomics reorder sums: 2e-5).  The competing launches cover the whole step and end by
+    themselves (each spins on the clock for `usec`)."""
+    import ctypes as C
+    from asr_amd import _lib, persist, streams
+    from asr_amd.Loss.label_smoothing import label_smoothing_loss
+    from asr_amd.Models.AttModel import AttModel
+    from oracle import ref_model as R
+    lib = _lib.load()
+    dev = _dev()
+    hp = R.make_hp(lmfb_dim=80, frame_stacking=3, num_hidden_nodes=320, num_encoder_layer=5, num_classes=1000,
+                   encoder_dropout=0.0)
+    torch.manual_seed(77)
+    m = AttModel(hp).to(dev).train()
+    B, T, L = 32, 500, 24
+    lengths = torch.linspace(T, 300, B).long()
+    x = torch.randn(B, T, 240)
+    for b in range(B):
+        x[b, lengths[b]:] = 0
+    x = x.to(dev)
+    tgt = torch.randint(0, 1000, (B, L)).to(dev)
+    tl = torch.linspace(L, L // 2, B).long().to(dev)
+
+    def step():
+        m.zero_grad(set_to_none=True)
+        loss = label_smoothing_loss(m(x, lengths, tgt), tgt, tl, hp.T_norm, hp.B_norm)
+        loss.backward()
+        return loss
+
+    was = streams.ENABLED
+    streams.enable(True)          # as the data-parallel job runs: weight gradients on the side stream
+    try:
+        step()
+        quiet = step()
+        torch.cuda.synchronize()
+        want = {k: p.grad.clone() for k, p in m.named_parameters()}
+        other = torch.cuda.Stream(device=dev)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        n_launch = max(8, int(60000 / usec))                      # ~60 ms of competing kernels, back to back
+        for _ in range(n_launch // 8):                            # a head start: they are resident when the step begins
+            _lib.check(lib.asr_debug_occupy(n_wg, threads, lds, usec, C.c_void_p(other.cuda_stream)))
+        e0.record()
+        for i in range(n_launch):
+            _lib.check(lib.asr_debug_occupy(n_wg, threads, lds, usec, C.c_void_p(other.cuda_stream)))
+            if i == n_launch // 8:
+                loss = step()
+                e1.record()
+        torch.cuda.synchronize()
+    finally:
+        streams.enable(was)
+    assert not persist.error_flags()
+    assert bool(torch.isfinite(loss)) and abs(float(loss) - float(quiet)) < 1e-5 * abs(float(quiet))
+    floor = 1e-3 * max(float(v.abs().max()) for v in want.values())
+    for k, p in m.named_parameters():
+        assert bool(torch.isfinite(p.grad).all()), k
+        err = float((p.grad - want[k]).abs().max())
+        assert err < 2e-5 * max(float(want[k].abs().max()), floor), (k, err)
+    assert e0.elapsed_time(e1) < 2000.0       # the step only waited; it did not sit out a 4 s wait bound
+
+
 def test_second_backward_raises_clearly():
     """The BLSTM backward consumes its saved gates in place and the decoder releases its saved
     tensors: a second pass over a retained graph must raise, not return wrong gradients."""
