@@ -334,41 +334,52 @@ class _BLSTMLayerFunction(torch.autograd.Function):
         # weight / bias gradients: nothing downstream reads them -> side stream, overlapping the
         # next layer's (latency-bound) recurrence kernel
         hout_two = (B, ho_b, ho_t)                 # row (t*B + b) <-> Hout element offset
-        grads = {}
         side_reads = (G, inp, Hout) + ((rl.rows,) if rl is not None else ())    # rows and prev share a block
+
+        def grad_w_hh(d):
+            # dW_hh[d] = sum_t dG_t^T h_{t-1}: forward pairs (t, t-1), reverse pairs (t, t+1);
+            # padded rows of dG and Hout are zero, so ragged lengths need no masking here
+            # (the row lists only skip their work)
+            gW = torch.empty(4 * H, H, **f32)
+            if T > 1:
+                K = (T - 1) * B
+                kl = None
+                if rl is not None:
+                    kl, K = (rl.prev, rl.n_prev) if d == 0 else (rl.rows, rl.n_next)
+                sk = ops.pick_splitk(4 * H, H, K)
+                if sk > 1:
+                    gW.zero_()
+                a_off = d * 4 * H + (B * 8 * H if d == 0 else 0)
+                b_off = d * H + (0 if d == 0 else ho_t)
+                ops.sgemm(dG, Hout, gW, 4 * H, H, K, a_mode=1, a_stride=8 * H, a_off=a_off, b_mode=1,
+                          b_two=hout_two, b_off=b_off, c_stride=H, splitk=sk, k_idx=kl)
+            else:
+                gW.zero_()
+            return gW
+
+        # The bottom layer's gradients are the one piece of side-stream work nothing hides: no recurrence follows it and
+        # the main stream would sit idle until the join.  With no input gradient to compute there, the main stream takes
+        # the two dW_hh products while the side stream does dW_ih and the bias sums (two queues fill the chip better
+        # than one: these are 30-50 tile split-K launches).
+        split_streams = first and not need_dx and streams.ENABLED and not any(p.grad is not None for p in ctx.wparams)
+        gW_main = [grad_w_hh(d) for d in range(2)] if split_streams else None
         with streams.on_side(dev, *side_reads, params=ctx.wparams):
             db = torch.empty(8 * H, **f32)
             ops.colsum(dG, db)                     # b_ih and b_hh receive the same column sums
             if ws is not None:                     # a timed-out wait in this backward: NaN gradients NOW, not garbage
                 persist.poison_from(ws, db)
-            for d in range(2):
-                # dW_hh[d] = sum_t dG_t^T h_{t-1}: forward pairs (t, t-1), reverse pairs (t, t+1);
-                # padded rows of dG and Hout are zero, so ragged lengths need no masking here
-                # (the row lists only skip their work)
-                gW = torch.empty(4 * H, H, **f32)
-                if T > 1:
-                    K = (T - 1) * B
-                    kl = None
-                    if rl is not None:
-                        kl, K = (rl.prev, rl.n_prev) if d == 0 else (rl.rows, rl.n_next)
-                    sk = ops.pick_splitk(4 * H, H, K)
-                    if sk > 1:
-                        gW.zero_()
-                    a_off = d * 4 * H + (B * 8 * H if d == 0 else 0)
-                    b_off = d * H + (0 if d == 0 else ho_t)
-                    ops.sgemm(dG, Hout, gW, 4 * H, H, K, a_mode=1, a_stride=8 * H, a_off=a_off, b_mode=1,
-                              b_two=hout_two, b_off=b_off, c_stride=H, splitk=sk, k_idx=kl)
-                else:
-                    gW.zero_()
-                # dW_ih[d] = dG[:, d]^T X
-                gWi = torch.empty(4 * H, D, **f32)
-                kl, K = (rl.rows, rl.n) if rl is not None else (None, T * B)
-                sk = ops.pick_splitk(4 * H, D, K)
-                if sk > 1:
-                    gWi.zero_()
-                ops.sgemm(dG, inp, gWi, 4 * H, D, K, a_mode=1, a_stride=8 * H, a_off=d * 4 * H, b_mode=1,
-                          b_two=in_two, c_stride=D, splitk=sk, k_idx=kl)
-                grads[d] = (gWi, gW, db[d * 4 * H:(d + 1) * 4 * H], db[d * 4 * H:(d + 1) * 4 * H].clone())
+            # dW_ih of BOTH directions in one product: dG^T (8H x K) @ X (K x D) -> [2][4H][D]
+            gWi = torch.empty(2, 4 * H, D, **f32)
+            kl, K = (rl.rows, rl.n) if rl is not None else (None, T * B)
+            sk = ops.pick_splitk(8 * H, D, K)
+            if sk > 1:
+                gWi.zero_()
+            ops.sgemm(dG, inp, gWi, 8 * H, D, K, a_mode=1, a_stride=8 * H, b_mode=1, b_two=in_two, c_stride=D,
+                      splitk=sk, k_idx=kl)
+            gW_hh = gW_main if split_streams else [grad_w_hh(d) for d in range(2)]
+            # (the clone reads db: it belongs on the stream that wrote it)
+            grads = {d: (gWi[d], gW_hh[d], db[d * 4 * H:(d + 1) * 4 * H], db[d * 4 * H:(d + 1) * 4 * H].clone())
+                     for d in range(2)}
         return (dIn, None, None, None, None, None, None, None, None) + grads[0] + grads[1]
 
 

@@ -1316,7 +1316,7 @@ static int g_blstm_pf = -1;
 static int blstm_prefetch_dist() {
     if (g_blstm_pf < 0) {
         const char *e = getenv("ASR_BLSTM_PREFETCH");
-        g_blstm_pf = e ? atoi(e) : 12;
+        g_blstm_pf = e ? atoi(e) : 16;
         if (g_blstm_pf < 0) g_blstm_pf = 0;
         if (g_blstm_pf > 255) g_blstm_pf = 255;
     }

@@ -285,7 +285,7 @@ int asr_blstm_xcd_groups(int mode);
 /* With the XCD-grouped grid, the workgroups of the unused XCD labels touch the saved activations (gates, cell states,
  * upstream gradient) `dist` time steps ahead of the recurrence, so that its own loads find them in the memory-side
  * cache instead of HBM (no counterpart in the reference; results are unaffected).  dist = 0 switches it off; returns
- * the previous value, a negative dist only queries.  Start-up value: environment variable ASR_BLSTM_PREFETCH (12). */
+ * the previous value, a negative dist only queries.  Start-up value: environment variable ASR_BLSTM_PREFETCH (16). */
 int asr_blstm_prefetch(int dist);
 int asr_blstm_fwd(const float *W_hh, float *G, float *Cs, float *Hout,
                   int64_t ho_t, int64_t ho_b, const int32_t *lengths,
