@@ -362,7 +362,6 @@ class _BLSTMLayerFunction(torch.autograd.Function):
         # the two dW_hh products while the side stream does dW_ih and the bias sums (two queues fill the chip better
         # than one: these are 30-50 tile split-K launches).
         split_streams = first and not need_dx and streams.ENABLED and not any(p.grad is not None for p in ctx.wparams)
-        gW_main = [grad_w_hh(d) for d in range(2)] if split_streams else None
         with streams.on_side(dev, *side_reads, params=ctx.wparams):
             db = torch.empty(8 * H, **f32)
             ops.colsum(dG, db)                     # b_ih and b_hh receive the same column sums
@@ -376,10 +375,11 @@ class _BLSTMLayerFunction(torch.autograd.Function):
                 gWi.zero_()
             ops.sgemm(dG, inp, gWi, 8 * H, D, K, a_mode=1, a_stride=8 * H, b_mode=1, b_two=in_two, c_stride=D,
                       splitk=sk, k_idx=kl)
-            gW_hh = gW_main if split_streams else [grad_w_hh(d) for d in range(2)]
-            # (the clone reads db: it belongs on the stream that wrote it)
-            grads = {d: (gWi[d], gW_hh[d], db[d * 4 * H:(d + 1) * 4 * H], db[d * 4 * H:(d + 1) * 4 * H].clone())
-                     for d in range(2)}
+            gW_hh = None if split_streams else [grad_w_hh(d) for d in range(2)]
+            db2 = db.clone()       # b_hh's copy (the clone reads db: it belongs on the stream that wrote it)
+        if split_streams:          # enqueued AFTER the side block: its entry event must not wait for these two
+            gW_hh = [grad_w_hh(d) for d in range(2)]
+        grads = {d: (gWi[d], gW_hh[d], db[d * 4 * H:(d + 1) * 4 * H], db2[d * 4 * H:(d + 1) * 4 * H]) for d in range(2)}
         return (dIn, None, None, None, None, None, None, None, None) + grads[0] + grads[1]
 
 
