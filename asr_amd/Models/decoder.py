@@ -49,9 +49,7 @@ class _AttDecFunction(torch.autograd.Function):
     # parameter order (state_dict order of the reference's Decoder)
     NAMES = ("W_se", "W_he", "b_he", "w_ee", "W_fe", "conv_w",
              "W_sy", "W_gy", "b_gy", "W_yy", "b_yy", "Emb", "W_ss", "W_gs", "b_gs")
-    # gradients the backward produces on the side stream (asr_amd/streams.py); the others on the main stream
-    SIDE = ("W_gs", "W_ss", "b_gs", "W_gy", "W_sy", "b_gy", "W_se", "Emb", "W_he", "b_he")
-
+    TRANSPOSED = ("W_se", "W_ss", "W_sy", "W_gs", "W_gy")     # read transposed by asr_attdec_bwd
     @staticmethod
     def forward(ctx, hbatch, lengths_dev, targets, *params):
         lib = _lib.load()
@@ -63,6 +61,19 @@ class _AttDecFunction(torch.autograd.Function):
         Hd = P["W_sy"].shape[0]
         V = P["W_yy"].shape[0]
         Y = torch.empty(B, L, V, device=hbatch.device, dtype=torch.float32)
+        # The backward loop reads five weights transposed.  They do not change between this forward and its backward:
+        # when the side stream is on, transpose them there NOW, under the forward loop, instead of in front of the
+        # backward loop on the critical path (5 launches, 25 us at the config-2 size).
+        ctx.WT = None
+        if streams.ENABLED and torch.is_grad_enabled():
+            dev = hbatch.device
+            side, main = streams.side_stream(dev), torch.cuda.current_stream(dev)
+            side.wait_stream(main)              # the parameters' last writer (the optimizer) ran on this stream
+            with torch.cuda.stream(side):
+                wt = tuple(ops.transpose(P[n]) for n in _AttDecFunction.TRANSPOSED)
+            ev = torch.cuda.Event()
+            ev.record(side)
+            ctx.WT = (wt, ev)
         ctx.parts = []
         for b0, b1 in batch_parts(lib, B, T, E, Hd, L):
             t, U = _AttDecFunction._forward_part(lib, P, hbatch[b0:b1], lengths_dev[b0:b1], targets[b0:b1], Y[b0:b1])
@@ -123,24 +134,30 @@ class _AttDecFunction(torch.autograd.Function):
         need_dh = ctx.needs_input_grad[0]
         dh = torch.empty(B, T, E, device=dY.device, dtype=torch.float32) if need_dh else None
         G = None
+        if ctx.WT is not None:                  # transposed on the side stream during the forward
+            WT, ev = ctx.WT
+            main = torch.cuda.current_stream(dY.device)
+            main.wait_event(ev)
+            for w in WT:
+                w.record_stream(main)
+        else:
+            WT = tuple(ops.transpose(ctx.P[n]) for n in _AttDecFunction.TRANSPOSED)
         for b0, b1, t, U in ctx.parts:
             Gp = _AttDecFunction._backward_part(lib, ctx.P, t, U, (b1 - b0, T, E, Hd, L, V), dY[b0:b1],
-                                                dh[b0:b1] if need_dh else None)
+                                                dh[b0:b1] if need_dh else None, WT)
             if G is None:
                 G = Gp
                 continue
-            # a further part of the batch: its weight gradients add to the first part's, each sum on the stream
-            # that produced its terms
-            side = [n for n in _AttDecFunction.NAMES if n in _AttDecFunction.SIDE]
-            main = [n for n in _AttDecFunction.NAMES if n not in _AttDecFunction.SIDE]
-            torch._foreach_add_([G[n] for n in main], [Gp[n] for n in main])
-            with streams.on_side(dY.device, *[Gp[n] for n in side], *[G[n] for n in side], params=tuple(ctx.P.values())):
-                torch._foreach_add_([G[n] for n in side], [Gp[n] for n in side])
-        ctx.parts = None
+            # a further part of the batch: its weight gradients add to the first part's, on the stream that produced
+            # both (every weight gradient of this node comes out of an on_side block)
+            names = _AttDecFunction.NAMES
+            with streams.on_side(dY.device, *[Gp[n] for n in names], *[G[n] for n in names], params=tuple(ctx.P.values())):
+                torch._foreach_add_([G[n] for n in names], [Gp[n] for n in names])
+        ctx.parts = ctx.WT = None
         return (dh, None, None) + tuple(G[n] for n in _AttDecFunction.NAMES)
 
     @staticmethod
-    def _backward_part(lib, P, t, U, dims, dY, dh):
+    def _backward_part(lib, P, t, U, dims, dY, dh, WT):
         """Gradients of one part of the batch: fills dh (when not None), returns the weight gradients by name."""
         B, T, E, Hd, L, V = dims
         A = 2 * Hd
@@ -149,24 +166,11 @@ class _AttDecFunction(torch.autograd.Function):
         S, g, alpha, hbatch = t["S"], t["g"], t["alpha"], t["hbatch"]
         u_two = (L, B * Hd, Hd)          # row (b*L + l) of youtput  <->  row (l*B + b) of U
         G = {}
-        # L_yy
-        dW_yy = torch.empty(V, Hd, **f32)
-        sk = ops.pick_splitk(V, Hd, B * L)
-        if sk > 1:
-            dW_yy.zero_()
-        ops.sgemm(dY, U, dW_yy, V, Hd, B * L, a_mode=1, a_stride=V, b_mode=1, b_two=u_two, c_stride=Hd,
-                  splitk=sk)
-        db_yy = torch.empty(V, **f32)
-        ops.colsum(dY.view(B * L, V), db_yy)
         dU = torch.empty(L, B, Hd, **f32)
         ops.sgemm(dY, P["W_yy"], dU, B * L, Hd, V, a_stride=V, b_mode=1, b_stride=Hd, c_two=u_two)
         dyp = ops.mul_dtanh(dU, U)
         # the loop
-        W_seT = ops.transpose(P["W_se"])
-        W_ssT = ops.transpose(P["W_ss"])
-        W_syT = ops.transpose(P["W_sy"])
-        W_gsT = ops.transpose(P["W_gs"])
-        W_gyT = ops.transpose(P["W_gy"])
+        W_seT, W_ssT, W_syT, W_gsT, W_gyT = WT
         drec = torch.empty(L, B, 4 * Hd, **f32)
         dsp = torch.empty(L, B, A, **f32)
         dg = torch.empty(L, B, E, **f32)
@@ -183,6 +187,7 @@ class _AttDecFunction(torch.autograd.Function):
                          dsp=dsp, dg=dg, de=de, dF=dF, dPH=dPH, dw_ee=dw_ee, dW_fe=dW_fe, dconv_w=dconv,
                          ws=ws).items():
             setattr(a, k, v.data_ptr())
+        a.defer_tail = 1        # dw_ee, dW_fe, dconv: asr_attdec_bwd_tail in the side block below
         check(lib.asr_attdec_bwd(C.byref(a), _stream()))
         # a timed-out in-launch wait of the persistent loop kernel turns dPH (-> every encoder gradient) into NaN
         check(lib.asr_poison_if_flag(ws.data_ptr() + 4 * int(lib.asr_attdec_bwd_err_offset(B, T, E, Hd, L)),
@@ -206,7 +211,18 @@ class _AttDecFunction(torch.autograd.Function):
             return out
 
         idx = t["targets"].t().contiguous().view(-1)
-        with streams.on_side(dev, S, g, drec, dyp, dsp, dPH, hbatch, idx, params=tuple(P.values())):
+        with streams.on_side(dev, S, g, drec, dyp, dsp, dPH, hbatch, idx, dY, U, ws, dF, alpha, de, params=tuple(P.values())):
+            # L_yy
+            G["W_yy"] = torch.empty(V, Hd, **f32)
+            sk = ops.pick_splitk(V, Hd, B * L)
+            if sk > 1:
+                G["W_yy"].zero_()
+            ops.sgemm(dY, U, G["W_yy"], V, Hd, B * L, a_mode=1, a_stride=V, b_mode=1, b_two=u_two, c_stride=Hd,
+                      splitk=sk)
+            G["b_yy"] = torch.empty(V, **f32)
+            ops.colsum(dY.view(B * L, V), G["b_yy"])
+            # the attention's own small weights (reads ws, dF, alpha)
+            check(lib.asr_attdec_bwd_tail(C.byref(a), _stream()))
             G["W_gs"] = tn(drec2, g2)
             G["W_ss"] = tn(drec2, S_in)
             G["b_gs"] = torch.empty(4 * Hd, **f32)
@@ -222,8 +238,7 @@ class _AttDecFunction(torch.autograd.Function):
             G["b_he"] = torch.empty(A, **f32)
             ops.colsum(dPH2, G["b_he"])
         G["w_ee"], G["W_fe"], G["conv_w"] = dw_ee, dW_fe, dconv
-        G["W_yy"], G["b_yy"] = dW_yy, db_yy
-        assert set(_AttDecFunction.SIDE) | {"w_ee", "W_fe", "conv_w", "W_yy", "b_yy"} == set(_AttDecFunction.NAMES)
+        assert set(G) == set(_AttDecFunction.NAMES)
         return G
 
 

@@ -72,6 +72,7 @@ class AttDecBwdArgs(C.Structure):
         ("drec", c_f), ("dsp", c_f), ("dg", c_f), ("de", c_f), ("dF", c_f),
         ("dPH", c_f), ("dw_ee", c_f), ("dW_fe", c_f), ("dconv_w", c_f),
         ("ws", c_f),
+        ("defer_tail", C.c_int),
     ]
 
 
@@ -136,6 +137,7 @@ SYMBOLS = {
     "asr_attdec_bwd_ws_floats": (c_i64, [C.c_int] * 5),
     "asr_attdec_bwd_err_offset": (c_i64, [C.c_int] * 5),
     "asr_attdec_bwd": (C.c_int, [C.POINTER(AttDecBwdArgs), c_f]),
+    "asr_attdec_bwd_tail": (C.c_int, [C.POINTER(AttDecBwdArgs), c_f]),
     # Conformer encoder (csrc/conformer.hip)
     "asr_layernorm_fwd": (C.c_int, [c_f] * 6 + [c_i64, C.c_int, C.c_float, c_f]),
     "asr_layernorm_bwd_blocks": (c_i64, [c_i64]),

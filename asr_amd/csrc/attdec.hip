@@ -1332,6 +1332,27 @@ static int attdec_fwd_persist_hf(int B, int T, int E, int Hd, int n_cu) {
     return ok ? hf : 0;
 }
 
+// One launch instead of four or five memsets in front of a decoder pass: zero up to three float ranges and one word,
+// fill the exchange area with 0xFF (every exchanged float starts with the "wrong" epoch tag).  Sizes in floats;
+// pointers 16-byte aligned or null.
+__global__ __launch_bounds__(256) void attdec_init_kernel(float *z0, int64_t n0, float *z1, int64_t n1, float *z2, int64_t n2,
+                                                          unsigned *word, float *ff, int64_t nff) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n0) z0[i] = 0.f;
+    if (i < n1) z1[i] = 0.f;
+    if (i < n2) z2[i] = 0.f;
+    if (i == 0 && word != nullptr) *word = 0u;
+    if (4 * i + 3 < nff) reinterpret_cast<uint4 *>(ff)[i] = make_uint4(0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu);
+    else for (int64_t e = 4 * i; e < nff; ++e) reinterpret_cast<unsigned *>(ff)[e] = 0xffffffffu;
+}
+static void attdec_init(float *z0, int64_t n0, float *z1, int64_t n1, float *z2, int64_t n2, unsigned *word, float *ff,
+                        int64_t nff, hipStream_t st) {
+    int64_t n = std::max(std::max(n0, n1), std::max(n2, (nff + 3) / 4));
+    if (n < 1) n = 1;
+    hipLaunchKernelGGL(attdec_init_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, z0, n0, z1, n1, z2, n2, word,
+                       ff, nff);
+}
+
 struct GreedyParams {
     const float *W_sy, *W_gy, *b_gy, *W_yy, *b_yy;
     int64_t *tokens;
@@ -1360,10 +1381,8 @@ static int run_attdec_fwd(const asr_attdec_fwd_args *a, const GreedyParams *gp, 
     const int A16p = (A + 15) & ~15;
     float *e_buf = a->ws;
     float *tab = a->ws + ((BT + 3) & ~(int64_t)3) + 64;   // padded W_fe / w_ee tables of the v2 energy kernel
-    ASR_CHECK_HIP(hipMemsetAsync(a->S, 0, sizeof(float) * BH, st));
-    ASR_CHECK_HIP(hipMemsetAsync(a->C, 0, sizeof(float) * BH, st));
-    ASR_CHECK_HIP(hipMemsetAsync(a->sproj, 0, sizeof(float) * BA, st));
-    ASR_CHECK_HIP(hipMemsetAsync(a->ws + asr_attdec_err_offset(B, T, E, Hd, L), 0, sizeof(unsigned), st));
+    unsigned *err_word = reinterpret_cast<unsigned *>(a->ws + asr_attdec_err_offset(B, T, E, Hd, L));
+    bool inited = false;        // S[0], C[0], sproj[0], the error word (and the exchange area): one launch, below
     const int vecPH = al16(a->PH) && A % 4 == 0;
     const size_t esm2 = energy_fwd2_smem(A);
     const bool use_v2 = vecPH && esm2 <= 150 * 1024;
@@ -1429,7 +1448,8 @@ static int run_attdec_fwd(const asr_attdec_fwd_args *a, const GreedyParams *gp, 
             p.err = reinterpret_cast<unsigned *>(a->ws + asr_attdec_err_offset(B, T, E, Hd, L));
             p.stamps = g_attdec_stamps;
             // every exchanged float starts with the "wrong" epoch tag (LSB = 1)
-            ASR_CHECK_HIP(hipMemsetAsync(p.xch, 0xFF, sizeof(float) * (size_t)xfl, st));
+            attdec_init(a->S, BH, a->C, BH, a->sproj, BA, err_word, p.xch, xfl, st);
+            inited = true;
             if (hf > PD_HF) hipLaunchKernelGGL((attdec_fwd_persist_kernel<false, PD_HF_MAX>), dim3((unsigned)nwg), dim3(PD_THREADS), psm, st, p);
             else if (p.stamps) hipLaunchKernelGGL((attdec_fwd_persist_kernel<true, PD_HF>), dim3((unsigned)nwg), dim3(PD_THREADS), psm, st, p);
             else hipLaunchKernelGGL((attdec_fwd_persist_kernel<false, PD_HF>), dim3((unsigned)nwg), dim3(PD_THREADS), psm, st, p);
@@ -1437,6 +1457,7 @@ static int run_attdec_fwd(const asr_attdec_fwd_args *a, const GreedyParams *gp, 
             return ASR_OK;
         }
     }
+    if (!inited) attdec_init(a->S, BH, a->C, BH, a->sproj, BA, err_word, nullptr, 0, st);
     for (int s = 0; s < L; ++s) {
         const float *S_s = a->S + s * BH;
         float *sp_s = a->sproj + s * BA;
@@ -2861,6 +2882,8 @@ extern "C" int asr_attdec_plan(int B, int T, int E, int Hd, int L) {
     return (attdec_fwd_persist_hf(B, T, E, Hd, n_cu) > 0 ? 1 : 0) | (attdec_bwd_persist_ok(B, T, E, Hd, n_cu) ? 2 : 0);
 }
 
+extern "C" int asr_attdec_bwd_tail(const asr_attdec_bwd_args *a, void *stream);
+
 extern "C" int asr_attdec_bwd(const asr_attdec_bwd_args *a, void *stream) {
     ASR_CHECK_ARG(a != nullptr, "attdec_bwd: null args");
     const asr_attdec_fwd_args *f = &a->f;
@@ -2896,7 +2919,6 @@ extern "C" int asr_attdec_bwd(const asr_attdec_bwd_args *a, void *stream) {
     const int A16p = (A + 15) & ~15;
     float *tab = w;               w += (int64_t)A16p * 13 + 64;
     float *post = w;
-    ASR_CHECK_HIP(hipMemsetAsync(dC, 0, sizeof(float) * BH, st));
     const int vecPH = al16(f->PH) && A % 4 == 0;
     const size_t esm2 = energy_bwd2_smem(A);
     const bool use_v2 = vecPH && esm2 <= 150 * 1024;
@@ -2919,7 +2941,8 @@ extern "C" int asr_attdec_bwd(const asr_attdec_bwd_args *a, void *stream) {
     const size_t ds_smem = sizeof(float) * 16 * (size_t)A;
     const int ds_lds = (vecT && A % 4 == 0 && ds_smem <= 44 * 1024) ? 1 : 0;
     bool persistent = false;
-    ASR_CHECK_HIP(hipMemsetAsync(a->ws + asr_attdec_bwd_err_offset(B, T, E, Hd, L), 0, sizeof(unsigned), st));
+    unsigned *err_word = reinterpret_cast<unsigned *>(a->ws + asr_attdec_bwd_err_offset(B, T, E, Hd, L));
+    bool inited = false;        // dC, dsp_0, the error word (and the exchange area): one launch, below
     {   // one launch for the whole loop when every workgroup of the (B x frame tile) grid gets a compute unit of its own
         static int n_cu = -1;
         if (n_cu < 0) {
@@ -2974,13 +2997,15 @@ extern "C" int asr_attdec_bwd(const asr_attdec_bwd_args *a, void *stream) {
             p.xch_bytes = (int)(xfl * 4);
             p.err = reinterpret_cast<unsigned *>(a->ws + asr_attdec_bwd_err_offset(B, T, E, Hd, L));
             p.stamps = g_attdec_stamps;
-            ASR_CHECK_HIP(hipMemsetAsync(p.xch, 0xFF, sizeof(float) * (size_t)xfl, st));
+            attdec_init(dC, BH, a->dsp, BA, nullptr, 0, err_word, p.xch, xfl, st);
+            inited = true;
             if (p.stamps) hipLaunchKernelGGL(attdec_bwd_persist_kernel<true>, dim3((unsigned)nwg), dim3(PD_THREADS), psm, st, p);
             else hipLaunchKernelGGL(attdec_bwd_persist_kernel<false>, dim3((unsigned)nwg), dim3(PD_THREADS), psm, st, p);
             ASR_CHECK_LAUNCH("attdec_bwd_persist_kernel");
             persistent = true;
         }
     }
+    if (!inited) attdec_init(dC, BH, a->dsp, BA, nullptr, 0, err_word, nullptr, 0, st);
     for (int s = persistent ? -1 : L - 1; s >= 0; --s) {
         const bool has_next = s + 1 < L;
         hipLaunchKernelGGL(dscell_kernel, dim3(cdiv(Hd, 16), cdiv(B, 16)), dim3(1024), ds_lds ? ds_smem : 0, st, s, L,
@@ -3011,16 +3036,11 @@ extern "C" int asr_attdec_bwd(const asr_attdec_bwd_args *a, void *stream) {
                                a->dF + s * BT * NCH, dsp_part, B, T, A, vecPH);
         }
     }
-    // dsp_0 (needed for dW_se = sum_s dsp_s^T S_s; S_0 = 0 so only for completeness): reduce the partials
-    {
-        // reuse dscell's summation path is not possible at s = -1; S_0 == 0 makes dsp_0 irrelevant to
-        // every gradient, so it is defined as zero.
-        ASR_CHECK_HIP(hipMemsetAsync(a->dsp, 0, sizeof(float) * BA, st));
-    }
-    // dPH, dW_fe, dw_ee
+    // dsp_0 (it multiplies S_0 = 0 in dW_se = sum_s dsp_s^T S_s, irrelevant to every gradient) is defined as zero:
+    // cleared by attdec_init above; neither loop writes step 0's slab.
+    // dPH (the critical path: d hbatch needs it) and the per-(tile, utterance) partial sums of dW_fe / dw_ee
     {
         float *part = post;
-        float *sum11 = post + nt * BA * 11;
         if (A % 16 == 0)
             hipLaunchKernelGGL(phase2_mfma_kernel, dim3(nt, B, cdiv(A, 16 * P3_NAT)), dim3(256), 0, st, f->PH,
                                (const float *)f->sproj, (const float *)a->de, (const float *)f->Fc, f->w_ee,
@@ -3029,13 +3049,45 @@ extern "C" int asr_attdec_bwd(const asr_attdec_bwd_args *a, void *stream) {
             hipLaunchKernelGGL(phase2_kernel, dim3(nt, B, cdiv(A, P2_A)), dim3(256), 0, st, f->PH,
                                (const float *)f->sproj, (const float *)a->de, (const float *)f->Fc, f->w_ee,
                                f->W_fe, f->lengths, a->dPH, part, L, B, T, A);
+    }
+    ASR_CHECK_LAUNCH("attdec_bwd kernels");
+    if (a->defer_tail) return ASR_OK;      // the caller runs asr_attdec_bwd_tail (e.g. on a second stream)
+    return asr_attdec_bwd_tail(a, stream);
+}
+
+// The rest of asr_attdec_bwd: gradients of the attention's own small weights -- dW_fe, dw_ee (column sums over the
+// partials phase 2 left in the workspace) and dconv_w (from the saved dF and alpha).  Nothing in the backward pass
+// reads them, so a caller that set defer_tail may run this on another stream once the main call's work is complete
+// there (an event), overlapping the encoder's backward; it reads a->ws, a->dF, f.alpha, f.lengths.
+extern "C" int asr_attdec_bwd_tail(const asr_attdec_bwd_args *a, void *stream) {
+    ASR_CHECK_ARG(a != nullptr, "attdec_bwd_tail: null args");
+    const asr_attdec_fwd_args *f = &a->f;
+    const int B = f->B, T = f->T, E = f->E, Hd = f->Hd, L = f->L, A = 2 * Hd;
+    ASR_CHECK_ARG(B > 0 && T > 0 && E > 0 && Hd > 0 && L > 0, "attdec_bwd_tail: bad shape");
+    ASR_CHECK_ARG(f->alpha && f->lengths && a->dF && a->dw_ee && a->dW_fe && a->dconv_w && a->ws, "attdec_bwd_tail: null pointer");
+    hipStream_t st = (hipStream_t)stream;
+    const size_t csm = sizeof(float) * (size_t)(((T + KW + 3) & ~3) + (size_t)T * 12);
+    ASR_CHECK_ARG(csm <= 159 * 1024, "attdec_bwd_tail: T=%d exceeds the LDS budget", T);
+    static thread_local bool attr_set = false;
+    if (!attr_set) {
+        ASR_CHECK_HIP(hipFuncSetAttribute((const void *)dconv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024));
+        attr_set = true;
+    }
+    const int64_t BH = (int64_t)B * Hd, BT = (int64_t)B * T, BA = (int64_t)B * A;
+    const int64_t nt = bwd_ntile(T);
+    const int A16p = (A + 15) & ~15;
+    float *post = a->ws + (BT + 64) + (BH + 64) + (nt * BA + 64) + ((int64_t)A16p * 13 + 64);   // as laid out by asr_attdec_bwd
+    // dW_fe, dw_ee
+    {
+        float *part = post;
+        float *sum11 = post + nt * BA * 11;
         // deterministic two-stage column sum over the (tile, b) partials
         ASR_CHECK(asr_colsum(part, (int)(nt * B), A * 11, (int64_t)A * 11, 0, 0, sum11, 0,
                              sum11 + A * 11 + 64, stream));
         hipLaunchKernelGGL(split_fe_kernel, dim3(cdiv((int64_t)A * 11, 256)), dim3(256), 0, st,
                            (const float *)sum11, A, a->dw_ee, a->dW_fe);
     }
-    // conv filter gradient (stream order: runs after phase 2 has finished with `post`)
+    // conv filter gradient (stream order: runs after the column sums have finished with `post`)
     if (L > 1) {
         float *part = post;
         hipLaunchKernelGGL(dconv_kernel, dim3((L - 1) * B), dim3(128), csm, st, (const float *)a->dF,
@@ -3045,6 +3097,6 @@ extern "C" int asr_attdec_bwd(const asr_attdec_bwd_args *a, void *stream) {
     } else {
         ASR_CHECK_HIP(hipMemsetAsync(a->dconv_w, 0, sizeof(float) * NCH * KW, st));
     }
-    ASR_CHECK_LAUNCH("attdec_bwd kernels");
+    ASR_CHECK_LAUNCH("attdec_bwd_tail kernels");
     return ASR_OK;
 }

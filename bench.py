@@ -832,6 +832,7 @@ def main():
             "ms_per_step_is": "median of the per-step HIP-event durations of the timed region (max over ranks)",
             "ms_per_step_mean": mean_ms, "value_from_mean": total_frames / (mean_ms * 1e-3),
             "ms_per_step_min_max": [min(step_ms), max(step_ms)],
+            "ms_per_step_all": [round(v, 3) for v in step_ms],
             "ms_per_step_exact_f32": exact_ms,
             "value_exact_f32": (total_frames / (exact_ms * 1e-3)) if exact_ms else None,
             "ms_per_step_with_loss_item": item_ms,

@@ -532,6 +532,9 @@ typedef struct {
     float *dW_fe;             /* (A,10)   */
     float *dconv_w;           /* (10,100) */
     float *ws;                /* asr_attdec_bwd_ws_floats() floats */
+    /* != 0: asr_attdec_bwd leaves dw_ee, dW_fe and dconv_w (gradients of attention.py's own small weights; nothing in
+     * the backward pass reads them) to asr_attdec_bwd_tail, which the caller may run on another stream */
+    int defer_tail;
 } asr_attdec_bwd_args;
 
 int64_t asr_attdec_bwd_ws_floats(int B, int T, int E, int Hd, int L);
@@ -541,6 +544,10 @@ int asr_attdec_bwd(const asr_attdec_bwd_args *a, void *stream);
  * asr_attdec_bwd_err_offset: index (in floats) inside a->ws of a 4-byte word that is non-zero after the call iff an
  * in-launch wait timed out (gradients invalid) -- fold it into a gradient with asr_poison_if_flag. */
 int64_t asr_attdec_bwd_err_offset(int B, int T, int E, int Hd, int L);
+/* The weight-gradient tail of asr_attdec_bwd when a->defer_tail was set (autograd of Models/attention.py:22-28's
+ * L_fe, L_ee, F_conv1d): column sums of the partials the main call left in a->ws -> dW_fe, dw_ee; dconv_w from the
+ * saved dF and alpha.  Same args as the main call; must be ordered after it (same stream, or an event). */
+int asr_attdec_bwd_tail(const asr_attdec_bwd_args *a, void *stream);
 
 #ifdef __cplusplus
 }
