@@ -153,7 +153,7 @@ class _BLSTMLayerFunction(torch.autograd.Function):
     nxt: _Next to fill for the layer above (the output is then already dropped out) or None."""
 
     @staticmethod
-    def forward(ctx, inp, lengths_dev, rl, first, last, H, pre, nxt, in_drop, w_ih_f, w_hh_f, b_ih_f, b_hh_f,
+    def forward(ctx, inp, lengths_dev, rl, first, last, H, pre, nxt, in_drop, whh_cat, w_ih_f, w_hh_f, b_ih_f, b_hh_f,
                 w_ih_r, w_hh_r, b_ih_r, b_hh_r):
         """in_drop = (p, seed) or None: inverted dropout applied to the input inside this node (the
         dropout between two nn.LSTM layers, Models/encoder.py:26), so that its backward fuses into
@@ -195,7 +195,8 @@ class _BLSTMLayerFunction(torch.autograd.Function):
                 for d, (w_ih, b_ih, b_hh) in enumerate(((w_ih_f, b_ih_f, b_hh_f), (w_ih_r, b_ih_r, b_hh_r))):
                     ops.sgemm(inp, w_ih, G, nrows, 4 * H, D, a_two=in_two, b_stride=D, c_stride=8 * H,
                               c_off=d * 4 * H, bias1=b_ih, bias2=b_hh, m_idx=rows)
-        W_hh = torch.cat([w_hh_f, w_hh_r], 0)      # [2][4H][H]
+        # [2][4H][H]: nn.LSTM keeps the two directions' recurrent weights in separate tensors, the kernels read one
+        W_hh = whh_cat if whh_cat is not None else torch.cat([w_hh_f, w_hh_r], 0)
         if last:
             Hout = torch.empty(B, T, 2 * H, **f32)
             ho_t, ho_b = 2 * H, T * 2 * H
@@ -245,6 +246,7 @@ class _BLSTMLayerFunction(torch.autograd.Function):
             main.wait_stream(pipe)
             nxt.G = G_n
         ctx.save_for_backward(inp, G, Cs, Hout, lengths_dev, w_ih_f, w_hh_f, w_ih_r, w_hh_r)
+        ctx.W_hh = W_hh            # a copy of the weights as they are now: the backward reads it instead of concatenating again
         ctx.mask = mask
         ctx.wparams = (w_ih_f, w_hh_f, b_ih_f, b_hh_f, w_ih_r, w_hh_r, b_ih_r, b_hh_r)
         ctx.p = nxt.p if mask is not None else 0.0
@@ -277,7 +279,7 @@ class _BLSTMLayerFunction(torch.autograd.Function):
         else:
             dHout = dOut
         dc_ws = torch.empty(2 * B * H, **f32)
-        W_hh = torch.cat([w_hh_f, w_hh_r], 0).view(2, 4 * H, H)
+        W_hh = ctx.W_hh.view(2, 4 * H, H)
         ws = _persist_ws(lib, B, H, dev)
         wsp = 0 if ws is None else ws.data_ptr()
         # [2][H][4H] for the step-wise kernels; the reduce-scatter form reads W_hh only: no transposition on its chain
@@ -380,7 +382,8 @@ class _BLSTMLayerFunction(torch.autograd.Function):
         if split_streams:          # enqueued AFTER the side block: its entry event must not wait for these two
             gW_hh = [grad_w_hh(d) for d in range(2)]
         grads = {d: (gWi[d], gW_hh[d], db[d * 4 * H:(d + 1) * 4 * H], db2[d * 4 * H:(d + 1) * 4 * H]) for d in range(2)}
-        return (dIn, None, None, None, None, None, None, None, None) + grads[0] + grads[1]
+        ctx.W_hh = None
+        return (dIn, None, None, None, None, None, None, None, None, None) + grads[0] + grads[1]
 
 
 class _DropoutFunction(torch.autograd.Function):
@@ -432,13 +435,16 @@ class Encoder(nn.Module):
         pipelined = streams.ENABLED and PIPE_FWD and PIPE_CHUNKS > 1 and T >= PIPE_MIN_T
         pre = None
         in_drop = None        # dropout between layers: applied by the consuming layer (fused backward)
+        # (tried: concatenating all layers' [2][4H][H] recurrent weights on the side stream ahead of the layers -- the
+        # event wait costs what the 6 us launches save: 17.07 vs 17.02 ms per step; each layer concatenates its own)
+        whh = [None] * self.num_layers
         for layer in range(self.num_layers):
             last = layer == self.num_layers - 1
             nxt = None
             if pipelined and not last:
                 n = flat[8 * (layer + 1): 8 * (layer + 1) + 8]     # (w_ih, w_hh, b_ih, b_hh) x (fwd, rev)
                 nxt = _Next(n[0], n[2], n[3], n[4], n[6], n[7], p, seed + 7919 * layer)
-            h = _BLSTMLayerFunction.apply(h, lengths_dev, rl, layer == 0, last, self.hidden, pre, nxt, in_drop,
+            h = _BLSTMLayerFunction.apply(h, lengths_dev, rl, layer == 0, last, self.hidden, pre, nxt, in_drop, whh[layer],
                                           *flat[8 * layer: 8 * layer + 8])
             in_drop = (p, seed + 7919 * layer) if (nxt is None and p > 0.0 and not last) else None
             pre = nxt
