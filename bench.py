@@ -742,9 +742,11 @@ def main():
     evs = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     t0 = time.perf_counter()
     evs[0].record()
+    host_t = []
     for i in range(args.steps):
         loss = step()
         evs[i + 1].record()
+        host_t.append(time.perf_counter())
     barrier()
     dt = time.perf_counter() - t0
     step_ms = [evs[i].elapsed_time(evs[i + 1]) for i in range(args.steps)]
@@ -833,6 +835,7 @@ def main():
             "ms_per_step_mean": mean_ms, "value_from_mean": total_frames / (mean_ms * 1e-3),
             "ms_per_step_min_max": [min(step_ms), max(step_ms)],
             "ms_per_step_all": [round(v, 3) for v in step_ms],
+            "host_enqueue_ms_all": [round((b - a) * 1e3, 3) for a, b in zip([t0] + host_t[:-1], host_t)],
             "ms_per_step_exact_f32": exact_ms,
             "value_exact_f32": (total_frames / (exact_ms * 1e-3)) if exact_ms else None,
             "ms_per_step_with_loss_item": item_ms,
