@@ -65,7 +65,7 @@ class _AttDecFunction(torch.autograd.Function):
         # when the side stream is on, transpose them there NOW, under the forward loop, instead of in front of the
         # backward loop on the critical path (5 launches, 25 us at the config-2 size).
         ctx.WT = None
-        if streams.ENABLED and torch.is_grad_enabled():
+        if streams.ENABLED and any(ctx.needs_input_grad):       # (grad mode is always off inside Function.forward)
             dev = hbatch.device
             side, main = streams.side_stream(dev), torch.cuda.current_stream(dev)
             side.wait_stream(main)              # the parameters' last writer (the optimizer) ran on this stream

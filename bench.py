@@ -226,8 +226,9 @@ def roofline_probe(hp, dev, in_step=None):
                         "kernel": "blstm_bwd_rs_kernel", "shape": [T, B, H], "valid_frames": valid,
                         "avg_us": dt * 1e6, "alone_us": alone * 1e6, "timed": "in the step" if in_step else "alone",
                         "us_per_time_step": dt * 1e6 / T,
-                        "note": "dominant kernel of the step by total duration; latency-bound recurrence, in the "
-                                "step the side stream's weight-gradient GEMMs share its CUs"}
+                        "note": "dominant kernel of the step by total duration; latency-bound recurrence (500 dependent "
+                                "steps); in the step it runs ~13 % longer than alone: memory-system latency under the "
+                                "side stream's weight-gradient GEMMs (profiles/r3_pmc_mfma.txt)"}
     # (2) input-projection GEMM of an upper encoder layer: (T*B x 2H) @ (2H x 4H), fp32 MFMA
     M, N, K = T * B, 4 * H, 2 * H
     A = torch.randn(M, K, generator=g).to(dev)
