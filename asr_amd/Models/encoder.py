@@ -91,6 +91,7 @@ PIPE_BWD = os.environ.get("ASR_PIPE_BWD", "1") != "0"
 # One launch for both directions of a layer's input projection and of its dX (two-level views
 # over the separate forward / reverse parameter tensors); ASR_MERGE_DIRECTIONS=0 restores two.
 MERGE_DIRECTIONS = os.environ.get("ASR_MERGE_DIRECTIONS", "1") != "0"
+PACK_WEIGHTS = os.environ.get("ASR_PACK_WEIGHTS", "1") != "0"     # pre-split W_ih for the projection / dX products (A/B timing)
 ROW_LIST_MIN_PADDING = float(os.environ.get("ASR_ROW_LIST_MIN_PADDING", "0.04"))
 
 
@@ -178,6 +179,7 @@ class _BLSTMLayerFunction(torch.autograd.Function):
         st = _stream()
         f32 = dict(device=dev, dtype=torch.float32)
         Cs = torch.empty(T, B, 2, H, **f32)
+        w_pk = None
         if pre is not None and pre.G is not None:
             G, pre.G = pre.G, None
         else:
@@ -188,9 +190,15 @@ class _BLSTMLayerFunction(torch.autograd.Function):
             dw, db1, db2 = ops.elem_delta(w_ih_f, w_ih_r), ops.elem_delta(b_ih_f, b_ih_r), ops.elem_delta(b_hh_f, b_hh_r)
             if MERGE_DIRECTIONS and None not in (dw, db1, db2):
                 # both directions in one launch: the reverse direction's weights and biases are
-                # reached through the two-level row / bias maps, nothing is concatenated
+                # reached through the two-level row / bias maps, nothing is concatenated.  At sizes where asr_sgemm has
+                # a kernel for it, the weights go in PRE-SPLIT ({hi:lo} words of both directions, one small launch):
+                # every one of the M / 128 row tiles would otherwise split the same weights again; the backward's dX
+                # product reads the same copy
+                if PACK_WEIGHTS and ops.packed_ok(nrows, 8 * H):
+                    w_pk = ops.pack_hilo(w_ih_f, w_ih_r)
                 ops.sgemm(inp, w_ih_f, G, nrows, 8 * H, D, a_two=in_two, b_two=(4 * H, D, dw), c_stride=8 * H,
-                          bias1=b_ih_f, bias2=b_hh_f, bias_two=(4 * H, db1, db2), m_idx=rows)
+                          bias1=b_ih_f, bias2=b_hh_f, bias_two=(4 * H, db1, db2), m_idx=rows,
+                          b_pk=None if w_pk is None else (w_pk, D))
             else:
                 for d, (w_ih, b_ih, b_hh) in enumerate(((w_ih_f, b_ih_f, b_hh_f), (w_ih_r, b_ih_r, b_hh_r))):
                     ops.sgemm(inp, w_ih, G, nrows, 4 * H, D, a_two=in_two, b_stride=D, c_stride=8 * H,
@@ -246,6 +254,7 @@ class _BLSTMLayerFunction(torch.autograd.Function):
             main.wait_stream(pipe)
             nxt.G = G_n
         ctx.save_for_backward(inp, G, Cs, Hout, lengths_dev, w_ih_f, w_hh_f, w_ih_r, w_hh_r)
+        ctx.w_pk = w_pk
         ctx.W_hh = W_hh            # a copy of the weights as they are now: the backward reads it instead of concatenating again
         ctx.mask = mask
         ctx.wparams = (w_ih_f, w_hh_f, b_ih_f, b_hh_f, w_ih_r, w_hh_r, b_ih_r, b_hh_r)
@@ -302,7 +311,8 @@ class _BLSTMLayerFunction(torch.autograd.Function):
                 dw = ops.elem_delta(w_ih_f, w_ih_r)
                 if MERGE_DIRECTIONS and dw is not None:
                     ops.sgemm(dG, w_ih_f, dIn, nrows, D, 8 * H, a_stride=8 * H, b_mode=1, b_two=(4 * H, D, dw),
-                              c_two=in_two, m_idx=rows, keep=keep, keep_scale=ks)
+                              c_two=in_two, m_idx=rows, keep=keep, keep_scale=ks,
+                              b_pk=None if ctx.w_pk is None else (ctx.w_pk, D))
                 else:
                     for d, w_ih in enumerate((w_ih_f, w_ih_r)):
                         ops.sgemm(dG, w_ih, dIn, nrows, D, 4 * H, a_stride=8 * H, a_off=d * 4 * H, b_mode=1,
@@ -382,7 +392,7 @@ class _BLSTMLayerFunction(torch.autograd.Function):
         if split_streams:          # enqueued AFTER the side block: its entry event must not wait for these two
             gW_hh = [grad_w_hh(d) for d in range(2)]
         grads = {d: (gWi[d], gW_hh[d], db[d * 4 * H:(d + 1) * 4 * H], db2[d * 4 * H:(d + 1) * 4 * H]) for d in range(2)}
-        ctx.W_hh = None
+        ctx.W_hh = ctx.w_pk = None
         return (dIn, None, None, None, None, None, None, None, None, None) + grads[0] + grads[1]
 
 

@@ -35,6 +35,7 @@ class GemmDesc(C.Structure):
         ("batch_d", C.c_int), ("batch_a1", c_i64), ("batch_b1", c_i64), ("batch_c1", c_i64),
         ("pad_ok", C.c_int),
         ("a_span", c_i64), ("b_span", c_i64),
+        ("a_packed", C.c_int), ("b_packed", C.c_int),
     ]
 
 
@@ -103,6 +104,7 @@ SYMBOLS = {
                                        c_f, c_f, c_f, c_f, c_f]),
     "asr_grad_sqnorm": (C.c_int, [C.POINTER(TensorList), c_f, C.c_int, c_f, c_f]),
     "asr_clip_adam_step": (C.c_int, [C.POINTER(TensorList)] * 4 + [c_f] + [C.c_double] * 6 + [c_i64, c_f]),
+    "asr_pack_hilo": (C.c_int, [c_f, c_f, c_i64, c_f, c_f]),
     "asr_blstm_ws_floats": (c_i64, [C.c_int, C.c_int]),
     "asr_blstm_precision": (C.c_int, [C.c_int]),
     "asr_blstm_xcd_groups": (C.c_int, [C.c_int]),

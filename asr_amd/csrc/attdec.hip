@@ -1023,18 +1023,29 @@ __global__ __launch_bounds__(PD_THREADS) void attdec_fwd_persist_kernel(PDParams
             };
             PDTile c0 = ldt(mt0), c1 = ldt(mt0 + 1);
             float e = 0.f, e1 = 0.f;
+            // Software pipeline over the tile pairs: the three-MFMA chains of pair j + 1 are ISSUED before the
+            // transcendental work of pair j, so the matrix pipe runs under this wave's own 2^x / 1/x stream instead of
+            // in front of it (an MFMA holds the vector issue port for 8 of its 32 cycles only).
+            auto xmm = [&](const PDTile &t0_, const PDTile &t1_, int j, f32x4 &x0, f32x4 &x1) {
+                x0 = f32x4{phr[j].x, phr[j].y, phr[j].z, phr[j].w};
+                x1 = f32x4{phr[j + 1].x, phr[j + 1].y, phr[j + 1].z, phr[j + 1].w};
+                x0 = __builtin_amdgcn_mfma_f32_16x16x4f32(t0_.a0, fB[0], x0, 0, 0, 0);
+                x1 = __builtin_amdgcn_mfma_f32_16x16x4f32(t1_.a0, fB[0], x1, 0, 0, 0);
+                x0 = __builtin_amdgcn_mfma_f32_16x16x4f32(t0_.a1, fB[1], x0, 0, 0, 0);
+                x1 = __builtin_amdgcn_mfma_f32_16x16x4f32(t1_.a1, fB[1], x1, 0, 0, 0);
+                x0 = __builtin_amdgcn_mfma_f32_16x16x4f32(t0_.a2, fB[2], x0, 0, 0, 0);
+                x1 = __builtin_amdgcn_mfma_f32_16x16x4f32(t1_.a2, fB[2], x1, 0, 0, 0);
+            };
+            f32x4 x0, x1;
+            xmm(c0, c1, 0, x0, x1);
 #pragma unroll
             for (int j = 0; j < PD_MTP; j += 2) {
                 PDTile n0 = c0, n1 = c1;
-                if (j + 2 < PD_MTP) { n0 = ldt(mt0 + j + 2); n1 = ldt(mt0 + j + 3); }
-                f32x4 x0 = {phr[j].x, phr[j].y, phr[j].z, phr[j].w};
-                f32x4 x1 = {phr[j + 1].x, phr[j + 1].y, phr[j + 1].z, phr[j + 1].w};
-                x0 = __builtin_amdgcn_mfma_f32_16x16x4f32(c0.a0, fB[0], x0, 0, 0, 0);
-                x1 = __builtin_amdgcn_mfma_f32_16x16x4f32(c1.a0, fB[0], x1, 0, 0, 0);
-                x0 = __builtin_amdgcn_mfma_f32_16x16x4f32(c0.a1, fB[1], x0, 0, 0, 0);
-                x1 = __builtin_amdgcn_mfma_f32_16x16x4f32(c1.a1, fB[1], x1, 0, 0, 0);
-                x0 = __builtin_amdgcn_mfma_f32_16x16x4f32(c0.a2, fB[2], x0, 0, 0, 0);
-                x1 = __builtin_amdgcn_mfma_f32_16x16x4f32(c1.a2, fB[2], x1, 0, 0, 0);
+                f32x4 y0 = x0, y1 = x1;
+                if (j + 2 < PD_MTP) {
+                    n0 = ldt(mt0 + j + 2); n1 = ldt(mt0 + j + 3);
+                    xmm(n0, n1, j + 2, y0, y1);
+                }
                 float t[8];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) { t[r] = __builtin_amdgcn_exp2f(x0[r]); t[4 + r] = __builtin_amdgcn_exp2f(x1[r]); }
@@ -1045,6 +1056,7 @@ __global__ __launch_bounds__(PD_THREADS) void attdec_fwd_persist_kernel(PDParams
                 e += c0.w4.z * t[2]; e1 += c1.w4.z * t[6];
                 e += c0.w4.w * t[3]; e1 += c1.w4.w * t[7];
                 c0 = n0; c1 = n1;
+                x0 = y0; x1 = y1;
             }
             e += e1;
             e += __shfl_xor(e, 16, 64);
@@ -2718,19 +2730,28 @@ __global__ __launch_bounds__(PD_THREADS) void attdec_bwd_persist_kernel(PBParams
                 // dF^T[c = 4q + r][t = col] / de-less form, partial over a: four independent accumulation chains
                 f32x4 dF0 = {0.f, 0.f, 0.f, 0.f}, dF1 = {0.f, 0.f, 0.f, 0.f}, dF2 = {0.f, 0.f, 0.f, 0.f}, dF3 = {0.f, 0.f, 0.f, 0.f};
                 PBTile c0 = ldt(mt0), c1 = ldt(mt0 + 1);
+                // x = K2L (PH + sproj + F W_fe^T): PH is the accumulator input, sproj k-slot 10 (F[t][10] = 1).
+                // Software pipeline: pair j + 1's chains are issued before pair j's transcendental work (see the forward)
+                auto xmm = [&](const PBTile &t0_, const PBTile &t1_, int j, f32x4 &x0, f32x4 &x1) {
+                    x0 = f32x4{phr[j].x, phr[j].y, phr[j].z, phr[j].w};
+                    x1 = f32x4{phr[j + 1].x, phr[j + 1].y, phr[j + 1].z, phr[j + 1].w};
+                    x0 = __builtin_amdgcn_mfma_f32_16x16x4f32(t0_.a0, fB[0], x0, 0, 0, 0);
+                    x1 = __builtin_amdgcn_mfma_f32_16x16x4f32(t1_.a0, fB[0], x1, 0, 0, 0);
+                    x0 = __builtin_amdgcn_mfma_f32_16x16x4f32(t0_.a1, fB[1], x0, 0, 0, 0);
+                    x1 = __builtin_amdgcn_mfma_f32_16x16x4f32(t1_.a1, fB[1], x1, 0, 0, 0);
+                    x0 = __builtin_amdgcn_mfma_f32_16x16x4f32(t0_.a2, fB[2], x0, 0, 0, 0);
+                    x1 = __builtin_amdgcn_mfma_f32_16x16x4f32(t1_.a2, fB[2], x1, 0, 0, 0);
+                };
+                f32x4 x0, x1;
+                xmm(c0, c1, 0, x0, x1);
 #pragma unroll
                 for (int j = 0; j < PD_MTP; j += 2) {
                     PBTile n0 = c0, n1 = c1;
-                    if (j + 2 < PD_MTP) { n0 = ldt(mt0 + j + 2); n1 = ldt(mt0 + j + 3); }
-                    // x = K2L (PH + sproj + F W_fe^T): PH is the accumulator input, sproj k-slot 10 (F[t][10] = 1)
-                    f32x4 x0 = {phr[j].x, phr[j].y, phr[j].z, phr[j].w};
-                    f32x4 x1 = {phr[j + 1].x, phr[j + 1].y, phr[j + 1].z, phr[j + 1].w};
-                    x0 = __builtin_amdgcn_mfma_f32_16x16x4f32(c0.a0, fB[0], x0, 0, 0, 0);
-                    x1 = __builtin_amdgcn_mfma_f32_16x16x4f32(c1.a0, fB[0], x1, 0, 0, 0);
-                    x0 = __builtin_amdgcn_mfma_f32_16x16x4f32(c0.a1, fB[1], x0, 0, 0, 0);
-                    x1 = __builtin_amdgcn_mfma_f32_16x16x4f32(c1.a1, fB[1], x1, 0, 0, 0);
-                    x0 = __builtin_amdgcn_mfma_f32_16x16x4f32(c0.a2, fB[2], x0, 0, 0, 0);
-                    x1 = __builtin_amdgcn_mfma_f32_16x16x4f32(c1.a2, fB[2], x1, 0, 0, 0);
+                    f32x4 y0 = x0, y1 = x1;
+                    if (j + 2 < PD_MTP) {
+                        n0 = ldt(mt0 + j + 2); n1 = ldt(mt0 + j + 3);
+                        xmm(n0, n1, j + 2, y0, y1);
+                    }
                     // sech^2 / 4 = E / (1 + E)^2 = r (1 - r), r = 1 / (1 + E), E = 2^(-|x|); the 4 rides in de4 and w_ee[a]
                     // in the dF operand table and in the final dsp sum: two transcendentals + three VALU per element
                     float dp0[4], dp1[4];
@@ -2759,6 +2780,7 @@ __global__ __launch_bounds__(PD_THREADS) void attdec_bwd_persist_kernel(PBParams
                         m.dspl[tt * PD_AL + 16 * (mt0 + j + 1) + 4 * q + (col >> 2)] = t1_;
                     }
                     c0 = n0; c1 = n1;
+                    x0 = y0; x1 = y1;
                 }
 #pragma unroll
                 for (int r = 0; r < 4; ++r) m.dFl[(part * TT + tl) * 16 + 4 * q + r] = (dF0[r] + dF1[r]) + (dF2[r] + dF3[r]);

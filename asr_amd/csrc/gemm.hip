@@ -425,14 +425,23 @@ __device__ __forceinline__ void gemm_epilogue_v4(const asr_gemm_desc &d, float *
 template <int N>
 struct IntTag { static constexpr int value = N; };
 
-template <int R, int MODE, int NPROD, bool MASK>
+// PACKED: the operand arrives pre-split, one 32-bit word {bf16 hi : bf16 lo} per element (asr_pack_hilo; the same
+// split as bf_split, done once by a producer instead of by every tile that reads the element): two byte permutes
+// per pair instead of two conversions, two shifts and two subtractions.
+template <int R, int MODE, int NPROD, bool MASK, bool PACKED = false>
 __device__ __forceinline__ void store_slot_bf2(unsigned char *hi, unsigned char *lo, float4 v, unsigned okm, int i) {
     const int f = threadIdx.x + 256 * i;
     if (MASK) v = make_float4(__uint_as_float(__float_as_uint(v.x) & okm), __uint_as_float(__float_as_uint(v.y) & okm),
                     __uint_as_float(__float_as_uint(v.z) & okm), __uint_as_float(__float_as_uint(v.w) & okm));
     unsigned h0, l0, h1, l1;
-    bf_split(v.x, v.y, h0, l0);
-    bf_split(v.z, v.w, h1, l1);
+    if (PACKED) {
+        const unsigned wx = __float_as_uint(v.x), wy = __float_as_uint(v.y), wz = __float_as_uint(v.z), ww = __float_as_uint(v.w);
+        h0 = __builtin_amdgcn_perm(wy, wx, 0x07060302u); l0 = __builtin_amdgcn_perm(wy, wx, 0x05040100u);
+        h1 = __builtin_amdgcn_perm(ww, wz, 0x07060302u); l1 = __builtin_amdgcn_perm(ww, wz, 0x05040100u);
+    } else {
+        bf_split(v.x, v.y, h0, l0);
+        bf_split(v.z, v.w, h1, l1);
+    }
     const int off = MODE == 0 ? (f >> 3) * BF2_ROW0 + (f & 7) * 8 : (f / (R / 4)) * BF2_PITCH1(R) + (f % (R / 4)) * 8;
     *reinterpret_cast<u32x2g *>(hi + off) = u32x2g{h0, h1};
     if (NPROD > 1) *reinterpret_cast<u32x2g *>(lo + off) = u32x2g{l0, l1};
@@ -488,7 +497,8 @@ struct BufLoader {
     }
 };
 
-template <int BM, int BN, int AMODE, int BMODE, int NPROD, bool KLIST = false, bool BUFA = false, bool BUFB = false>
+// PK: bit 0 = the A operand, bit 1 = the B operand arrives as {hi:lo} words (asr_gemm_desc.a_packed / b_packed)
+template <int BM, int BN, int AMODE, int BMODE, int NPROD, bool KLIST = false, bool BUFA = false, bool BUFB = false, int PK = 0>
 __global__ __launch_bounds__(256, 2) void sgemm_bf3_kernel(asr_gemm_desc d, int ktiles_per_split, int flags) {
     constexpr int GK = BF_GK;
     constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
@@ -560,11 +570,11 @@ __global__ __launch_bounds__(256, 2) void sgemm_bf3_kernel(asr_gemm_desc d, int 
         const int k0 = kbeg + kt * GK;
         if (sl < NSA) {
             const unsigned ok = (BUFA || (la.base[sl] != nullptr && k0 + la.rk[sl] < kend)) ? 0xffffffffu : 0u;
-            store_slot_bf2<BM, AMODE, NPROD, !BUFA>(Ah[buf], Al[lb_], ra[s][sl], ok, sl);
+            store_slot_bf2<BM, AMODE, NPROD, !BUFA, (PK & 1) != 0>(Ah[buf], Al[lb_], ra[s][sl], ok, sl);
         } else {
             const int t = sl - NSA;
             const unsigned ok = (BUFB || (lb.base[t] != nullptr && k0 + lb.rk[t] < kend)) ? 0xffffffffu : 0u;
-            store_slot_bf2<BN, BMODE, NPROD, !BUFB>(Bh[buf], Bl[lb_], rb[s][t], ok, t);
+            store_slot_bf2<BN, BMODE, NPROD, !BUFB, (PK & 2) != 0>(Bh[buf], Bl[lb_], rb[s][t], ok, t);
         }
     };
     if (nk > 0) {
@@ -643,6 +653,28 @@ extern "C" int asr_gemm_precision(int mode) {
 }
 
 static bool aligned16(const void *p) { return (((uintptr_t)p) & 15) == 0; }
+
+// {hi:lo} words of one or two fp32 arrays (bf_split's arithmetic, element by element)
+__global__ __launch_bounds__(256) void pack_hilo_kernel(const float *__restrict__ s0, const float *__restrict__ s1, int64_t n,
+                                                        unsigned *__restrict__ dst) {
+    const int64_t tot = s1 ? 2 * n : n;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < tot; i += (int64_t)gridDim.x * 256) {
+        const float x = i < n ? s0[i] : s1[i - n];
+        unsigned hi, lo;
+        bf_split(x, 0.f, hi, lo);
+        dst[i] = (hi << 16) | (lo & 0xffffu);
+    }
+}
+extern "C" int asr_pack_hilo(const float *src0, const float *src1, int64_t n, float *dst, void *stream) {
+    ASR_CHECK_ARG(src0 && dst && n >= 0, "pack_hilo: bad argument");
+    if (n == 0) return ASR_OK;
+    const int64_t tot = src1 ? 2 * n : n;
+    const unsigned blocks = (unsigned)std::min<int64_t>((tot + 255) / 256, 4096);
+    hipLaunchKernelGGL(pack_hilo_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, src0, src1, n,
+                       reinterpret_cast<unsigned *>(dst));
+    ASR_CHECK_LAUNCH("pack_hilo_kernel");
+    return ASR_OK;
+}
 
 extern "C" int asr_sgemm(const asr_gemm_desc *din, void *stream) {
     ASR_CHECK_ARG(din != nullptr, "sgemm: null descriptor");
@@ -730,13 +762,23 @@ extern "C" int asr_sgemm(const asr_gemm_desc *din, void *stream) {
                            (d.c_s1 % 4 == 0) && (d.nbatch == 1 || (d.batch_c % 4 == 0 && (!two || d.batch_c1 % 4 == 0))) &&
                            (!d.c_keep || (((uintptr_t)d.c_keep) & 3) == 0);
         const int kflags = xcd_map | (vec_c ? 32 : 0);
+        // pre-split operands: only where a kernel is instantiated for them (128 x 128 tiles, buffer loads on both
+        // operands, bf16x3, A k-contiguous); the caller (asr_amd/ops.py) asks asr_sgemm_packed_ok first
+        const int pk = (din->a_packed ? 1 : 0) | (din->b_packed ? 2 : 0);
+        ASR_CHECK_ARG(pk == 0 || (prec == 1 && buf_a && buf_b && d.a_mode == 0 && !d.k_idx && pk != 1 && (pk == 2 || d.b_mode == 0) &&
+                                  d.M >= 128 && d.N >= 128 && (t128 >= 320 || (sk > 1 && t128 >= 256)) && bf_tile == 0),
+                      "sgemm: a_packed / b_packed set for a shape or mode without a pre-split kernel");
         // 128 x 128 tiles from 320 of them on (measured down to 375: tools/gemm_tile_pick.py; at 188 the 64 x 64 tile wins);
         // split-K launches sized for one resident round (asr_amd/ops.py pick_splitk) keep them from 256 on
         int shape = bf_tile ? bf_tile
                             : (d.M >= 128 && d.N >= 128 && (t128 >= 320 || (sk > 1 && t128 >= 256)) ? 1
                                                                                                    : (d.M >= 128 && t12864 >= 384 ? 2 : 3));
 #define BF_LAUNCH(BM_, BN_, AM, BM2, NP, KL)                                                                          \
-    if (buf_a && buf_b && !KL && NP == 3)                                                                             \
+    if (pk == 2 && BM_ == 128 && BN_ == 128 && AM == 0 && NP == 3 && !KL)                                             \
+        hipLaunchKernelGGL((sgemm_bf3_kernel<128, 128, 0, BM2, 3, false, true, true, 2>), grid, dim3(256), 0, st, d, perb, kflags); \
+    else if (pk == 3 && BM_ == 128 && BN_ == 128 && AM == 0 && BM2 == 0 && NP == 3 && !KL)                            \
+        hipLaunchKernelGGL((sgemm_bf3_kernel<128, 128, 0, 0, 3, false, true, true, 3>), grid, dim3(256), 0, st, d, perb, kflags); \
+    else if (buf_a && buf_b && !KL && NP == 3)                                                                        \
         hipLaunchKernelGGL((sgemm_bf3_kernel<BM_, BN_, AM, BM2, NP, false, true, true>), grid, dim3(256), 0, st, d, perb, kflags); \
     else if (buf_a && !KL && NP == 3)                                                                                 \
         hipLaunchKernelGGL((sgemm_bf3_kernel<BM_, BN_, AM, BM2, NP, false, true, false>), grid, dim3(256), 0, st, d, perb, kflags); \

@@ -49,7 +49,8 @@ def _span(t, off, rows, inner, dd, s0, s1, nbatch, batch, batch_d, batch1, liste
 def sgemm(A, B, Cm, M, N, K, *, a_mode=0, b_mode=0, a_stride=None, b_stride=None, c_stride=None,
           a_two=None, b_two=None, c_two=None, bias1=None, bias2=None, alpha=1.0, accumulate=False,
           act=0, splitk=1, nbatch=1, batch_a=0, batch_b=0, batch_c=0, a_off=0, b_off=0, c_off=0,
-          m_idx=None, k_idx=None, bias_two=None, keep=None, keep_scale=1.0, batch_two=None, pad_ok=0):
+          m_idx=None, k_idx=None, bias_two=None, keep=None, keep_scale=1.0, batch_two=None, pad_ok=0,
+          a_packed=False, b_packed=False, b_pk=None):
     """C[m,n] (+)= alpha * sum_k A(m,k) B(n,k) (+ biases); see include/asr_amd.h.
 
     *_stride: single row stride (elements); *_two = (d, s0, s1): two-level row
@@ -57,6 +58,9 @@ def sgemm(A, B, Cm, M, N, K, *, a_mode=0, b_mode=0, a_stride=None, b_stride=None
     m_idx / k_idx: int32 device row lists (M resp. K then count list entries).
     bias_two = (d, s1_bias1, s1_bias2): two-level bias index.  keep / keep_scale: uint8 mask laid
     out like C, applied to the stored value (fused dropout backward).
+    b_pk = (packed tensor, row stride): a pre-split copy of the WHOLE B operand (pack_hilo; single-level rows, same
+    b_mode), used instead of B when the library has a kernel for it at this shape (packed_ok, buffer loads possible),
+    silently ignored otherwise -- the result is bit-identical either way.
     """
     lib = _lib.load()
     d = GemmDesc()
@@ -88,6 +92,7 @@ def sgemm(A, B, Cm, M, N, K, *, a_mode=0, b_mode=0, a_stride=None, b_stride=None
     # batch_two = (batch_d, a1, b1, c1): two-level batch index, see include/asr_amd.h
     d.batch_d, d.batch_a1, d.batch_b1, d.batch_c1 = (0, 0, 0, 0) if batch_two is None else batch_two
     d.pad_ok = pad_ok
+    d.a_packed, d.b_packed = int(a_packed), int(b_packed)
     # readable span of A and B from their pointers, when every element the views can name lies inside the tensor
     # (a two-level view may step into ANOTHER allocation, e.g. the reverse direction's weights: then 0 = unknown)
     bd, ba1, bb1 = (d.batch_d, d.batch_a1, d.batch_b1) if batch_two is not None else (0, 0, 0)
@@ -95,6 +100,12 @@ def sgemm(A, B, Cm, M, N, K, *, a_mode=0, b_mode=0, a_stride=None, b_stride=None
                      nbatch, batch_a, bd, ba1, m_idx is not None or (k_idx is not None and a_mode == 1))
     d.b_span = _span(B, b_off, N if b_mode == 0 else K, K if b_mode == 0 else N, d.b_d, d.b_s0, d.b_s1,
                      nbatch, batch_b, bd, bb1, k_idx is not None and b_mode == 1)
+    if (b_pk is not None and not a_packed and a_mode == 0 and k_idx is None and nbatch == 1 and splitk == 1
+            and d.a_span > 0 and d.a_span < 0x7ffffff0 and packed_ok(M, N)):
+        Bp, bps = b_pk
+        span = _span(Bp, 0, N if b_mode == 0 else K, K if b_mode == 0 else N, 0, bps, 0, 1, 0, 0, 0, False)
+        if span > 0 and span < 0x7ffffff0 and (b_mode == 0 or K * bps * 4 < 0x7ffffff0):
+            d.B, d.b_d, d.b_s0, d.b_s1, d.b_span, d.b_packed = Bp.data_ptr(), 0, bps, 0, span, 1
     for name, idx, n in (("m_idx", m_idx, M), ("k_idx", k_idx, K)):
         if idx is None:
             setattr(d, name, 0)
@@ -106,6 +117,28 @@ def sgemm(A, B, Cm, M, N, K, *, a_mode=0, b_mode=0, a_stride=None, b_stride=None
 
 
 GEMM_MODES = {"f32": 0, "bf16x3": 1, "bf16": 2}
+
+
+def packed_ok(M, N):
+    """True when asr_sgemm has a pre-split-operand kernel for an (M x N) product with a k-contiguous A: the bf16x3
+    mode, 128 x 128 tiles (asr_sgemm picks them from 320 tiles on) and no tile override in the environment."""
+    import os
+    return (_lib.load().asr_gemm_precision(-1) == 1 and M >= 128 and N >= 128
+            and ((M + 127) // 128) * ((N + 127) // 128) >= 320 and not os.environ.get("ASR_GEMM_BF_TILE")
+            and os.environ.get("ASR_GEMM_BUF", "1") != "0" and os.environ.get("ASR_GEMM_PACKED", "1") != "0")
+
+
+def pack_hilo(src0, src1=None):
+    """{bf16 hi : bf16 lo} words (stored in a float32 tensor) of src0, followed by src1's when given: the
+    pre-split operand form of asr_sgemm (b_packed)."""
+    src0 = _req(src0).contiguous()
+    n = src0.numel()
+    if src1 is not None:
+        src1 = _req(src1).contiguous()
+        assert src1.numel() == n
+    out = torch.empty((2 if src1 is not None else 1) * n, device=src0.device, dtype=torch.float32)
+    check(_lib.load().asr_pack_hilo(_p(src0), _p(src1), n, _p(out), _stream()))
+    return out
 
 
 class gemm_precision:

@@ -156,6 +156,11 @@ typedef struct {
      * are given and below 2 GiB the bf16 kernels fetch the operands with range-checked buffer loads (no per-load
      * address arithmetic or masks); results are identical either way. */
     int64_t a_span, b_span;
+    /* != 0: the operand holds pre-split elements, one 32-bit word {bf16 hi : bf16 lo} each (asr_pack_hilo) instead of
+     * fp32 -- the bf16x3 split done once by a producer instead of by every tile that reads the element.  Only with
+     * asr_gemm_precision 1, a_mode 0, known spans, 128 x 128 tiles (>= 320 of them) and b_packed alone or both
+     * (a_packed alone has no kernel): anything else is rejected, ask asr_amd/ops.py::packed_ok.  Bit-identical results. */
+    int a_packed, b_packed;
 } asr_gemm_desc;
 
 int asr_sgemm(const asr_gemm_desc *d, void *stream);
@@ -169,6 +174,10 @@ int asr_sgemm(const asr_gemm_desc *d, void *stream);
  * ASR_GEMM_PRECISION = f32 | bf16x3 | bf16 (default bf16x3).  Shapes outside the fast path (unaligned
  * operands, K < 32) use mode 0 whatever the setting. */
 int asr_gemm_precision(int mode);
+/* dst[i] = {bf16 hi : bf16 lo} of src0[i] for i < n, of src1[i - n] for n <= i < 2n (src1 may be NULL: n words only):
+ * the pre-split form asr_gemm_desc.a_packed / b_packed reads; two sources so that the forward and the reverse
+ * direction's weight_ih of an nn.LSTM layer (Models/encoder.py:25) land in one contiguous [2][4H][D] operand. */
+int asr_pack_hilo(const float *src0, const float *src1, int64_t n, float *dst, void *stream);
 
 /* small helpers used by the backward passes (bias gradients, layouts) */
 /* out[n] (+)= sum_m A[rowoff(m) + n]; accumulate != 0 keeps the old value.

@@ -119,6 +119,50 @@ def test_sgemm_row_lists(R, N, K, keep, gemm_mode):
         ops.sgemm(Xd, Wd, out, n, N, K, a_stride=K, b_stride=K, c_stride=N, k_idx=idx)
 
 
+@pytest.mark.parametrize("M,N,K,b_mode", [(12800, 2560, 640, 0), (12800, 640, 2560, 1), (56000, 128, 96, 0)])
+def test_sgemm_presplit_weights_bit_identical(M, N, K, b_mode):
+    """asr_sgemm with the B operand handed over pre-split (asr_pack_hilo: one {bf16 hi : bf16 lo} word per element,
+    the split done once instead of by every row tile) against the same product splitting fp32 operands on the fly:
+    the arithmetic is the same, so the results are bit for bit equal -- with a row list and a bias as the encoder's
+    projection uses them, and with both operands pre-split.  In exact-fp32 mode the packed copy is ignored."""
+    from asr_amd import ops
+    dev = _dev()
+    g = torch.Generator().manual_seed(M + N)
+    A = torch.randn(M, K, generator=g).to(dev)
+    W = (torch.randn(N, K, generator=g) if b_mode == 0 else torch.randn(K, N, generator=g)).to(dev)
+    bias = torch.randn(N, generator=g).to(dev)
+    rows = torch.arange(0, M, 1, dtype=torch.int32)[torch.rand(M, generator=g) < 0.8].to(dev)
+    Wp = ops.pack_hilo(W).view_as(W)
+    w_words = Wp.view(torch.int32)
+    w_bits = W.view(torch.int32)
+    assert bool(((w_words >> 16) - (w_bits >> 16)).abs().max() <= 1)          # the hi half is bf16(x): top 16 bits, rounded
+    bs = K if b_mode == 0 else N
+    assert ops.packed_ok(rows.numel(), N)
+    outs = []
+    for pk in (None, (Wp, bs)):
+        C_ = torch.full((M, N), 7.0, device=dev)
+        ops.sgemm(A, W, C_, rows.numel(), N, K, a_stride=K, b_mode=b_mode, b_stride=bs, c_stride=N, bias1=bias,
+                  m_idx=rows, b_pk=pk)
+        outs.append(C_)
+    assert torch.equal(outs[0], outs[1])
+    assert float((outs[0][rows.long()] - 7.0).abs().max()) > 0 and bool((outs[0] == 7.0).any())     # unlisted rows untouched
+    want = A.double()[rows.long()] @ (W.double().t() if b_mode == 0 else W.double()) + bias.double()
+    assert rel_err(outs[1][rows.long()].cpu(), want.cpu()) < 2e-5
+    if b_mode == 0:
+        Ap = ops.pack_hilo(A).view_as(A)
+        C2 = torch.empty(M, N, device=dev)
+        C3 = torch.empty(M, N, device=dev)
+        ops.sgemm(Ap, Wp, C2, M, N, K, a_stride=K, b_stride=K, c_stride=N, a_packed=True, b_packed=True)
+        ops.sgemm(A, W, C3, M, N, K, a_stride=K, b_stride=K, c_stride=N)
+        assert torch.equal(C2, C3)
+    with ops.gemm_precision("f32"):          # no pre-split kernel in this mode: the fp32 operand is used
+        C4 = torch.empty(M, N, device=dev)
+        ops.sgemm(A, W, C4, M, N, K, a_stride=K, b_mode=b_mode, b_stride=bs, c_stride=N, b_pk=(Wp, bs))
+        want = A.double() @ (W.double().t() if b_mode == 0 else W.double())
+        assert rel_err(C4.cpu(), want.cpu()) < 5e-6          # fp32 accumulation over up to 2560 terms
+
+
+
 def test_sgemm_two_tensor_operand_and_fused_keep(gemm_mode):
     """One launch over two separately allocated weight / bias tensors (two-level views), and the
     dropout-backward mask applied in the epilogue."""
