@@ -2021,6 +2021,7 @@ __global__ __launch_bounds__(256) void phase2_kernel(
 // (the sum over f may visit the 16 frames in any order: k-step r takes frame 4*(lane>>4)+r,
 // which is exactly what the lane holds in the C/D layout -- no transpose).
 #define P3_NAT 2
+template <bool vecF>
 __global__ __launch_bounds__(256) void phase2_mfma_kernel(
     const float *__restrict__ PH, const float *__restrict__ sproj /* (L,B,A) */,
     const float *__restrict__ de /* (L,B,T) */, const float *__restrict__ Fc /* (L,B,T,NCH) */,
@@ -2067,69 +2068,80 @@ __global__ __launch_bounds__(256) void phase2_mfma_kernel(
     // Per-step inputs (the tile's 64 x 10 conv features, 64 energy gradients, 16*P3_NAT state
     // projections) are staged through LDS once per workgroup -- loading them per lane costs ~13
     // scattered vector-memory instructions per wave and step, which bound the first version.
-    // Double-buffered: step s+1's global loads are in flight under step s's math; one barrier
-    // per step.  Frames at or past the utterance length are staged as zeros.
-    // 16-byte loads of the contiguous [64][10] block: its offset ((s*B+b)*T + t0)*10 floats is a
-    // multiple of 4 when T is even (t0 is a multiple of 64)
-    const bool vecF = (T & 1) == 0 && (((uintptr_t)Fc) & 15) == 0;
-    float4 stF = zero4();
-    float stF1[3] = {0.f, 0.f, 0.f};
-    float stD = 0.f, stS = 0.f;
-    auto fetch = [&](int s) {
-        const int64_t sb = (int64_t)s * B + b;
-        const float *fp = Fc + (sb * T + t0) * NCH;
-        const int nfl = (min(len, t0 + 64) - t0) * NCH;   // valid floats of the block
-        if (vecF) {
-            if (tid < 160) {
-                const int e = tid * 4;
-                if (e + 3 < nfl) {
-                    stF = ld4(fp + e);
-                } else {   // ragged end of the utterance inside this tile
-                    stF = make_float4(e < nfl ? fp[e] : 0.f, e + 1 < nfl ? fp[e + 1] : 0.f,
-                                      e + 2 < nfl ? fp[e + 2] : 0.f, 0.f);
-                }
-            }
-        } else {
+    // Double-buffered in LDS, two register sets in flight, one barrier per step.  Frames at or past
+    // the utterance length are staged as zeros.
+    // Every thread has one role for the whole pass (threads 0..159: one 16-byte piece of the F block; 160..223: one
+    // energy gradient; 224..255: one state projection) and issues the same three range-checked buffer loads each
+    // step, the ones outside its role at an out-of-range offset (they return 0 and move no data).  No branch sits
+    // between a load and its use, so the loads of step s+2 stay in flight under the math of step s: with the
+    // per-lane branches of the earlier version the compiler drained the vector-memory counter at every join,
+    // which exposed the full load latency in every step (0.89 -> 0.69 ms at config 2 inside the step; the rest
+    // is the math: 14 fp32 MFMAs and 8 tanh per wave and step, measured 0.67 ms with the staging removed).
+    static_assert(16 * P3_NAT <= 32, "state-projection loaders are threads 224..255");
+    // vecF (host: T even and Fc 16-byte aligned): the F block's offset ((s*B+b)*T + t0)*NCH floats is a multiple of 4
+    constexpr int P3_OOB = 0x7ffffff0;
+    const int nfl = (min(len, t0 + 64) - t0) * NCH;   // valid floats of the tile's [64][NCH] block
+    int offF[3];
+    bool keepF[4];
+    if constexpr (vecF) {
+        const int e = tid * 4;
+        offF[0] = (tid < 160 && e < nfl) ? e * 4 : P3_OOB;
+        offF[1] = offF[2] = P3_OOB;
 #pragma unroll
-            for (int j = 0; j < 3; ++j) {
-                const int e = tid + 256 * j;
-                stF1[j] = (e < 640 && e < nfl) ? fp[e] : 0.f;
-            }
+        for (int j = 0; j < 4; ++j) keepF[j] = e + j < nfl;   // an utterance may end inside the 16 bytes
+    } else {
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const int e = tid + 256 * j;
+            offF[j] = (e < 640 && e < nfl) ? e * 4 : P3_OOB;
         }
-        if (tid >= 160 && tid < 224) {
-            const int t = t0 + tid - 160;
-            stD = t < len ? de[sb * T + t] : 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) keepF[j] = true;
+    }
+    const int offD = (tid >= 160 && tid < 224 && t0 + tid - 160 < len) ? (tid - 160) * 4 : P3_OOB;
+    const int offS = (tid >= 224 && tid - 224 < 16 * P3_NAT && a_base + tid - 224 < A) ? (tid - 224) * 4 : P3_OOB;
+    // one descriptor per array for the whole pass (host: L*B*T*NCH*4 < 2 GiB); a step moves the scalar offset only
+    const int row0 = b * T + t0;                                   // step 0's first frame
+    __amdgpu_buffer_rsrc_t dF = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(Fc), 0, L * B * T * NCH * 4, 0x00020000);
+    __amdgpu_buffer_rsrc_t dD = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(de), 0, L * B * T * 4, 0x00020000);
+    __amdgpu_buffer_rsrc_t dS = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(sproj), 0, L * B * A * 4, 0x00020000);
+#pragma unroll
+    for (int j = 0; j < 3; ++j) if (offF[j] != P3_OOB) offF[j] += row0 * NCH * 4;
+    const int voffD = offD != P3_OOB ? offD + row0 * 4 : P3_OOB;
+    const int voffS = offS != P3_OOB ? offS + (b * A + a_base) * 4 : P3_OOB;
+    const int stepF = B * T * NCH * 4, stepD = B * T * 4, stepS = B * A * 4;
+    auto fetch = [&](int s, pd_u32x4 &rF, unsigned &rF1, unsigned &rF2, unsigned &rD, unsigned &rS) {
+        if constexpr (vecF) {
+            rF = __builtin_amdgcn_raw_buffer_load_b128(dF, offF[0], s * stepF, 0);
+        } else {
+            rF[0] = __builtin_amdgcn_raw_buffer_load_b32(dF, offF[0], s * stepF, 0);
+            rF1 = __builtin_amdgcn_raw_buffer_load_b32(dF, offF[1], s * stepF, 0);
+            rF2 = __builtin_amdgcn_raw_buffer_load_b32(dF, offF[2], s * stepF, 0);
         }
-        if (tid < 16 * P3_NAT) {
-            const int a = a_base + tid;
-            stS = a < A ? sproj[sb * A + a] : 0.f;
-        }
+        rD = __builtin_amdgcn_raw_buffer_load_b32(dD, voffD, s * stepD, 0);
+        rS = __builtin_amdgcn_raw_buffer_load_b32(dS, voffS, s * stepS, 0);
     };
-    __shared__ __attribute__((aligned(16))) float Fs[2][64][12];
+    // the F block is staged as it lies in memory ([64][NCH], no row padding); the k-padding of the 12-wide
+    // products is applied when the fragments are read
+    __shared__ __attribute__((aligned(16))) float Fs[2][64 * NCH];
     __shared__ __attribute__((aligned(16))) float des[2][64];
-    __shared__ float sps[2][16 * P3_NAT];
-    auto stage = [&](int buf) {
-        if (vecF) {
+    __shared__ float sps[2][32];
+    auto stage = [&](int buf, const pd_u32x4 &rF, unsigned rF1, unsigned rF2, unsigned rD, unsigned rS) {
+        if constexpr (vecF) {
             if (tid < 160) {
-                const float w[4] = {stF.x, stF.y, stF.z, stF.w};
+                pd_u32x4 v = rF;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int e = tid * 4 + j;
-                    Fs[buf][e / NCH][e % NCH] = w[j];
-                }
+                for (int j = 0; j < 4; ++j) v[j] = keepF[j] ? v[j] : 0u;
+                *reinterpret_cast<pd_u32x4 *>(&Fs[buf][tid * 4]) = v;
             }
         } else {
-#pragma unroll
-            for (int j = 0; j < 3; ++j) {
-                const int e = tid + 256 * j;
-                if (e < 640) Fs[buf][e / NCH][e % NCH] = stF1[j];
-            }
+            Fs[buf][tid] = __uint_as_float(rF[0]);
+            Fs[buf][tid + 256] = __uint_as_float(rF1);
+            if (tid < 128) Fs[buf][tid + 512] = __uint_as_float(rF2);
         }
-        if (tid >= 160 && tid < 224) des[buf][tid - 160] = stD;
-        if (tid < 16 * P3_NAT) sps[buf][tid] = stS;
+        if (tid >= 160 && tid < 224) des[buf][tid - 160] = __uint_as_float(rD);
+        if (tid >= 224) sps[buf][tid - 224] = __uint_as_float(rS);
     };
-    // columns 10, 11 of Fs are the k-padding of the 12-wide products: zero once
-    for (int i2 = tid; i2 < 2 * 64; i2 += 256) { Fs[i2 >> 6][i2 & 63][10] = 0.f; Fs[i2 >> 6][i2 & 63][11] = 0.f; }
     float acc_ph[P3_NAT][4], acc_ee[P3_NAT];
     f32x4 acc_fe[P3_NAT];
 #pragma unroll
@@ -2139,12 +2151,24 @@ __global__ __launch_bounds__(256) void phase2_mfma_kernel(
 #pragma unroll
         for (int r = 0; r < 4; ++r) acc_ph[n][r] = 0.f;
     }
-    fetch(0);
-    stage(0);
-    __syncthreads();
-    for (int s = 0; s < L; ++s) {
+    // fragment addresses and padding predicates (step-invariant)
+    int ia[3], ib[4];
+    bool ka[3];
+#pragma unroll
+    for (int ks = 0; ks < 3; ++ks) {
+        ka[ks] = 4 * ks + q < NCH;
+        ia[ks] = (16 * wave + col) * NCH + min(4 * ks + q, NCH - 1);
+    }
+    const bool kb = col < NCH;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) ib[r] = (16 * wave + 4 * q + r) * NCH + min(col, NCH - 1);
+    // one label step: (nF..) holds step s+1's rows (loaded one step ago), (fF..) is free and takes step s+2's
+    auto step = [&](int s, pd_u32x4 &nF, unsigned &nF1, unsigned &nF2, unsigned &nD, unsigned &nS,
+                    pd_u32x4 &fF, unsigned &fF1, unsigned &fF2, unsigned &fD, unsigned &fS) {
         const int buf = s & 1;
-        if (s + 1 < L) fetch(s + 1);                       // uniform
+        // unconditional (the last two steps fetch step L-1 again): a branch here would make the compiler count the
+        // outstanding loads for its not-taken side, i.e. wait for these new loads too before the staging below
+        fetch(min(s + 2, L - 1), fF, fF1, fF2, fD, fS);
         const float4 dv = *reinterpret_cast<const float4 *>(&des[buf][16 * wave + 4 * q]);
         const float dev[4] = {dv.x, dv.y, dv.z, dv.w};
         // every term of this step carries a factor de[f]: a wave whose 16 frames all have de == 0
@@ -2154,9 +2178,9 @@ __global__ __launch_bounds__(256) void phase2_mfma_kernel(
         if (live) {
         float fa[3], ff[4];
 #pragma unroll
-        for (int ks = 0; ks < 3; ++ks) fa[ks] = Fs[buf][16 * wave + col][4 * ks + q];
+        for (int ks = 0; ks < 3; ++ks) { const float v = Fs[buf][ia[ks]]; fa[ks] = ka[ks] ? v : 0.f; }
 #pragma unroll
-        for (int r = 0; r < 4; ++r) ff[r] = col < 12 ? Fs[buf][16 * wave + 4 * q + r][min(col, 11)] : 0.f;
+        for (int r = 0; r < 4; ++r) { const float v = Fs[buf][ib[r]]; ff[r] = kb ? v : 0.f; }
 #pragma unroll
         for (int n = 0; n < P3_NAT; ++n) {
             const float spv = sps[buf][16 * n + col];
@@ -2176,8 +2200,18 @@ __global__ __launch_bounds__(256) void phase2_mfma_kernel(
                 acc_fe[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(ff[r], dp[r], acc_fe[n], 0, 0, 0);
         }
         }
-        if (s + 1 < L) stage(buf ^ 1);
+        stage(buf ^ 1, nF, nF1, nF2, nD, nS);            // after the last step: a copy nobody reads
         __syncthreads();
+    };
+    pd_u32x4 F0 = {0u, 0u, 0u, 0u}, F1v = {0u, 0u, 0u, 0u};
+    unsigned a1 = 0, a2 = 0, aD = 0, aS = 0, b1 = 0, b2 = 0, bD = 0, bS = 0;
+    fetch(0, F0, a1, a2, aD, aS);
+    stage(0, F0, a1, a2, aD, aS);
+    fetch(min(1, L - 1), F1v, b1, b2, bD, bS);
+    __syncthreads();
+    for (int s = 0; s < L; s += 2) {
+        step(s, F1v, b1, b2, bD, bS, F0, a1, a2, aD, aS);
+        if (s + 1 < L) step(s + 1, F0, a1, a2, aD, aS, F1v, b1, b2, bD, bS);
     }
 #pragma unroll
     for (int n = 0; n < P3_NAT; ++n) {
@@ -3063,8 +3097,13 @@ extern "C" int asr_attdec_bwd(const asr_attdec_bwd_args *a, void *stream) {
     // dPH (the critical path: d hbatch needs it) and the per-(tile, utterance) partial sums of dW_fe / dw_ee
     {
         float *part = post;
-        if (A % 16 == 0)
-            hipLaunchKernelGGL(phase2_mfma_kernel, dim3(nt, B, cdiv(A, 16 * P3_NAT)), dim3(256), 0, st, f->PH,
+        const bool p3 = A % 16 == 0 && (int64_t)L * B * T * NCH * 4 < (1ll << 31) && (int64_t)L * B * A * 4 < (1ll << 31);
+        if (p3 && (T & 1) == 0 && (((uintptr_t)f->Fc) & 15) == 0)
+            hipLaunchKernelGGL(phase2_mfma_kernel<true>, dim3(nt, B, cdiv(A, 16 * P3_NAT)), dim3(256), 0, st, f->PH,
+                               (const float *)f->sproj, (const float *)a->de, (const float *)f->Fc, f->w_ee,
+                               f->W_fe, f->lengths, a->dPH, part, L, B, T, A);
+        else if (p3)
+            hipLaunchKernelGGL(phase2_mfma_kernel<false>, dim3(nt, B, cdiv(A, 16 * P3_NAT)), dim3(256), 0, st, f->PH,
                                (const float *)f->sproj, (const float *)a->de, (const float *)f->Fc, f->w_ee,
                                f->W_fe, f->lengths, a->dPH, part, L, B, T, A);
         else
