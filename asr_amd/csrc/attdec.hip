@@ -2012,22 +2012,28 @@ __global__ __launch_bounds__(256) void phase2_kernel(
     }
 }
 
-// The same pass on the matrix cores (A % 16 == 0).  grid (ceil(T/64), B, ceil(A/64)), block 256:
-// wave w owns frames [16w, 16w+16) of the 64-frame tile and P3_NAT 16-column tiles of attention
-// units, all L steps with the accumulators in registers.  Per step and column tile:
-//   x[f][a]   = PH + sproj + sum_c F[f][c] W_fe[a][c]     3 x v_mfma_f32_16x16x4 (c padded to 12)
-//   dpre[f][a] = de[f] w_ee[a] (1 - tanh^2 x)              VALU, C/D layout: lane = (a, 4 frames)
-//   dW_fe^T[c][a] += sum_f F[f][c] dpre[f][a]              4 x MFMA, the lane's own dpre as B operand
-// (the sum over f may visit the 16 frames in any order: k-step r takes frame 4*(lane>>4)+r,
-// which is exactly what the lane holds in the C/D layout -- no transpose).
+// The same pass in 16 x 16 tiles (A % 16 == 0).  grid (ceil(T/64), B, ceil(A/32)), block 256: wave w owns frames
+// [16w, 16w+16) of the 64-frame tile and the two 16-column tiles of attention units, all L steps with the
+// accumulators in registers; lane = (unit a = lane & 15 of each tile, frames 4q .. 4q+3 with q = lane >> 4).  Per
+// step, frame and unit:
+//   x      = PH + sproj + sum_c F[f][c] W_fe[a][c]
+//   dpre   = de[f] w_ee[a] (1 - tanh^2 x);   dPH += dpre;   dw_ee += de[f] tanh x
+//   dW_fe[a][c] += F[f][c] dpre              (the lane's own four frames; summed over q and the waves at the end)
+// with the two column tiles paired in packed-fp32 operations (v_pk_fma_f32).  The first versions ran the two
+// 10-wide products on v_mfma_f32_16x16x4_f32 (K padded to 12: 3 + 4 instructions per tile and step); measured,
+// the matrix pipe's 14 x 32 cycles per wave and step did not hide under the other waves' VALU work, and the
+// pass is VALU-issue-bound either way (2 transcendentals + ~7 VALU per element): 96 packed FMAs cost less
+// (0.87 -> 0.77 ms with every label step live, tools/dec_time.py).
 #define P3_NAT 2
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 template <bool vecF>
-__global__ __launch_bounds__(256) void phase2_mfma_kernel(
+__global__ __launch_bounds__(256) void phase2_tile_kernel(
     const float *__restrict__ PH, const float *__restrict__ sproj /* (L,B,A) */,
     const float *__restrict__ de /* (L,B,T) */, const float *__restrict__ Fc /* (L,B,T,NCH) */,
     const float *__restrict__ w_ee, const float *__restrict__ W_fe, const int32_t *__restrict__ lengths,
     float *__restrict__ dPH, float *__restrict__ part /* [tile*B + b][A][11] */, int L, int B, int T, int A) {
-    __shared__ float fe_s[4][P3_NAT][16][17];
+    static_assert(P3_NAT == 2, "the two column tiles are paired in packed fp32 operations");
+    __shared__ float fe_s[4][P3_NAT][NCH][17];
     __shared__ float ee_s[4][P3_NAT][16];
     const int b = blockIdx.y, t0 = blockIdx.x * 64;
     const int len = min(lengths[b], T);
@@ -2047,23 +2053,22 @@ __global__ __launch_bounds__(256) void phase2_mfma_kernel(
         }
         return;
     }
-    float wee[P3_NAT], wfe[P3_NAT][3], ph[P3_NAT][4];
-    bool av[P3_NAT];
+    // step-invariant operands, {tile 0, tile 1} pairs; columns past A carry zeros
+    const int a0 = a_base + col, a1 = a_base + 16 + col;
+    const bool av[P3_NAT] = {a0 < A, a1 < A};
+    const f32x2 wee2 = {av[0] ? w_ee[a0] : 0.f, av[1] ? w_ee[a1] : 0.f};
+    f32x2 wfe2[NCH], afe[NCH], ph2[4], acc_ph2[4], acc_ee2 = {0.f, 0.f};
 #pragma unroll
-    for (int n = 0; n < P3_NAT; ++n) {
-        const int a = a_base + 16 * n + col;
-        av[n] = a < A;
-        wee[n] = av[n] ? w_ee[a] : 0.f;
+    for (int c = 0; c < NCH; ++c) {
+        wfe2[c] = f32x2{av[0] ? W_fe[a0 * NCH + c] : 0.f, av[1] ? W_fe[a1 * NCH + c] : 0.f};
+        afe[c] = f32x2{0.f, 0.f};
+    }
 #pragma unroll
-        for (int ks = 0; ks < 3; ++ks) {
-            const int c = 4 * ks + q;
-            wfe[n][ks] = (av[n] && c < NCH) ? W_fe[a * NCH + c] : 0.f;
-        }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int t = tf + 4 * q + r;
-            ph[n][r] = (av[n] && t < len) ? PH[((int64_t)b * T + t) * A + a] : 0.f;
-        }
+    for (int r = 0; r < 4; ++r) {
+        const int t = tf + 4 * q + r;
+        ph2[r] = f32x2{(av[0] && t < len) ? PH[((int64_t)b * T + t) * A + a0] : 0.f,
+                       (av[1] && t < len) ? PH[((int64_t)b * T + t) * A + a1] : 0.f};
+        acc_ph2[r] = f32x2{0.f, 0.f};
     }
     // Per-step inputs (the tile's 64 x 10 conv features, 64 energy gradients, 16*P3_NAT state
     // projections) are staged through LDS once per workgroup -- loading them per lane costs ~13
@@ -2075,8 +2080,8 @@ __global__ __launch_bounds__(256) void phase2_mfma_kernel(
     // step, the ones outside its role at an out-of-range offset (they return 0 and move no data).  No branch sits
     // between a load and its use, so the loads of step s+2 stay in flight under the math of step s: with the
     // per-lane branches of the earlier version the compiler drained the vector-memory counter at every join,
-    // which exposed the full load latency in every step (0.89 -> 0.69 ms at config 2 inside the step; the rest
-    // is the math: 14 fp32 MFMAs and 8 tanh per wave and step, measured 0.67 ms with the staging removed).
+    // which exposed the full load latency in every step (0.89 -> 0.69 ms at config 2 inside the step; with the
+    // math switched off the staging skeleton alone takes 0.17 ms).
     static_assert(16 * P3_NAT <= 32, "state-projection loaders are threads 224..255");
     // vecF (host: T even and Fc 16-byte aligned): the F block's offset ((s*B+b)*T + t0)*NCH floats is a multiple of 4
     constexpr int P3_OOB = 0x7ffffff0;
@@ -2121,8 +2126,7 @@ __global__ __launch_bounds__(256) void phase2_mfma_kernel(
         rD = __builtin_amdgcn_raw_buffer_load_b32(dD, voffD, s * stepD, 0);
         rS = __builtin_amdgcn_raw_buffer_load_b32(dS, voffS, s * stepS, 0);
     };
-    // the F block is staged as it lies in memory ([64][NCH], no row padding); the k-padding of the 12-wide
-    // products is applied when the fragments are read
+    // the F block is staged as it lies in memory ([64][NCH], no row padding)
     __shared__ __attribute__((aligned(16))) float Fs[2][64 * NCH];
     __shared__ __attribute__((aligned(16))) float des[2][64];
     __shared__ float sps[2][32];
@@ -2142,26 +2146,6 @@ __global__ __launch_bounds__(256) void phase2_mfma_kernel(
         if (tid >= 160 && tid < 224) des[buf][tid - 160] = __uint_as_float(rD);
         if (tid >= 224) sps[buf][tid - 224] = __uint_as_float(rS);
     };
-    float acc_ph[P3_NAT][4], acc_ee[P3_NAT];
-    f32x4 acc_fe[P3_NAT];
-#pragma unroll
-    for (int n = 0; n < P3_NAT; ++n) {
-        acc_ee[n] = 0.f;
-        acc_fe[n] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int r = 0; r < 4; ++r) acc_ph[n][r] = 0.f;
-    }
-    // fragment addresses and padding predicates (step-invariant)
-    int ia[3], ib[4];
-    bool ka[3];
-#pragma unroll
-    for (int ks = 0; ks < 3; ++ks) {
-        ka[ks] = 4 * ks + q < NCH;
-        ia[ks] = (16 * wave + col) * NCH + min(4 * ks + q, NCH - 1);
-    }
-    const bool kb = col < NCH;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) ib[r] = (16 * wave + 4 * q + r) * NCH + min(col, NCH - 1);
     // one label step: (nF..) holds step s+1's rows (loaded one step ago), (fF..) is free and takes step s+2's
     auto step = [&](int s, pd_u32x4 &nF, unsigned &nF1, unsigned &nF2, unsigned &nD, unsigned &nS,
                     pd_u32x4 &fF, unsigned &fF1, unsigned &fF2, unsigned &fD, unsigned &fS) {
@@ -2176,42 +2160,41 @@ __global__ __launch_bounds__(256) void phase2_mfma_kernel(
         // length) adds exact zeros -- skip its math (wave-uniform), keep the barrier
         const bool live = __any(dv.x != 0.f || dv.y != 0.f || dv.z != 0.f || dv.w != 0.f);
         if (live) {
-        float fa[3], ff[4];
+        // the lane's four frames (rows 4q .. 4q+3 of the wave's 16) are 40 contiguous floats of the staged block;
+        // the 16 lanes of a column group read the same addresses (LDS broadcast)
+        const float4 *Fr = reinterpret_cast<const float4 *>(&Fs[buf][(16 * wave + 4 * q) * NCH]);
+        float Fv[4 * NCH];
 #pragma unroll
-        for (int ks = 0; ks < 3; ++ks) { const float v = Fs[buf][ia[ks]]; fa[ks] = ka[ks] ? v : 0.f; }
+        for (int i = 0; i < NCH; ++i) {
+            const float4 t4 = Fr[i];
+            Fv[4 * i] = t4.x; Fv[4 * i + 1] = t4.y; Fv[4 * i + 2] = t4.z; Fv[4 * i + 3] = t4.w;
+        }
+        const f32x2 spv = {sps[buf][col], sps[buf][16 + col]};
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { const float v = Fs[buf][ib[r]]; ff[r] = kb ? v : 0.f; }
+        for (int r = 0; r < 4; ++r) {
+            f32x2 x = ph2[r] + spv;
 #pragma unroll
-        for (int n = 0; n < P3_NAT; ++n) {
-            const float spv = sps[buf][16 * n + col];
-            f32x4 x = {ph[n][0] + spv, ph[n][1] + spv, ph[n][2] + spv, ph[n][3] + spv};
+            for (int c = 0; c < NCH; ++c) x += Fv[r * NCH + c] * wfe2[c];
+            const f32x2 th = {tanh_f(x.x), tanh_f(x.y)};
+            const f32x2 dp = dev[r] * (1.f - th * th) * wee2;
+            acc_ph2[r] += dp;
+            acc_ee2 += dev[r] * th;
 #pragma unroll
-            for (int ks = 0; ks < 3; ++ks) x = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[ks], wfe[n][ks], x, 0, 0, 0);
-            float dp[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float th = tanh_f(x[r]);
-                dp[r] = dev[r] * (1.f - th * th) * wee[n];
-                acc_ph[n][r] += dp[r];
-                acc_ee[n] += dev[r] * th;
-            }
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-                acc_fe[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(ff[r], dp[r], acc_fe[n], 0, 0, 0);
+            for (int c = 0; c < NCH; ++c) afe[c] += Fv[r * NCH + c] * dp;
         }
         }
         stage(buf ^ 1, nF, nF1, nF2, nD, nS);            // after the last step: a copy nobody reads
         __syncthreads();
     };
     pd_u32x4 F0 = {0u, 0u, 0u, 0u}, F1v = {0u, 0u, 0u, 0u};
-    unsigned a1 = 0, a2 = 0, aD = 0, aS = 0, b1 = 0, b2 = 0, bD = 0, bS = 0;
-    fetch(0, F0, a1, a2, aD, aS);
-    stage(0, F0, a1, a2, aD, aS);
-    fetch(min(1, L - 1), F1v, b1, b2, bD, bS);
+    unsigned p1 = 0, p2 = 0, pD = 0, pS = 0, r1 = 0, r2 = 0, rD = 0, rS = 0;
+    fetch(0, F0, p1, p2, pD, pS);
+    stage(0, F0, p1, p2, pD, pS);
+    fetch(min(1, L - 1), F1v, r1, r2, rD, rS);
     __syncthreads();
     for (int s = 0; s < L; s += 2) {
-        step(s, F1v, b1, b2, bD, bS, F0, a1, a2, aD, aS);
-        if (s + 1 < L) step(s + 1, F0, a1, a2, aD, aS, F1v, b1, b2, bD, bS);
+        step(s, F1v, r1, r2, rD, rS, F0, p1, p2, pD, pS);
+        if (s + 1 < L) step(s + 1, F0, p1, p2, pD, pS, F1v, r1, r2, rD, rS);
     }
 #pragma unroll
     for (int n = 0; n < P3_NAT; ++n) {
@@ -2219,14 +2202,19 @@ __global__ __launch_bounds__(256) void phase2_mfma_kernel(
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int t = tf + 4 * q + r;
-            if (av[n] && t < T) dPH[((int64_t)b * T + t) * A + a] = acc_ph[n][r];
+            if (av[n] && t < T) dPH[((int64_t)b * T + t) * A + a] = acc_ph2[r][n];
         }
-        float e = acc_ee[n];
+        float e = acc_ee2[n];
         e += __shfl_xor(e, 16, 64);
         e += __shfl_xor(e, 32, 64);
         if (q == 0) ee_s[wave][n][col] = e;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) fe_s[wave][n][4 * q + r][col] = acc_fe[n][r];   // [c][a]
+        for (int c = 0; c < NCH; ++c) {     // the lane's sum over its four frames -> the wave's sixteen
+            float v = afe[c][n];
+            v += __shfl_xor(v, 16, 64);
+            v += __shfl_xor(v, 32, 64);
+            if (q == 0) fe_s[wave][n][c][col] = v;
+        }
     }
     __syncthreads();
     for (int i = tid; i < 16 * P3_NAT * 11; i += 256) {
@@ -3099,11 +3087,11 @@ extern "C" int asr_attdec_bwd(const asr_attdec_bwd_args *a, void *stream) {
         float *part = post;
         const bool p3 = A % 16 == 0 && (int64_t)L * B * T * NCH * 4 < (1ll << 31) && (int64_t)L * B * A * 4 < (1ll << 31);
         if (p3 && (T & 1) == 0 && (((uintptr_t)f->Fc) & 15) == 0)
-            hipLaunchKernelGGL(phase2_mfma_kernel<true>, dim3(nt, B, cdiv(A, 16 * P3_NAT)), dim3(256), 0, st, f->PH,
+            hipLaunchKernelGGL(phase2_tile_kernel<true>, dim3(nt, B, cdiv(A, 16 * P3_NAT)), dim3(256), 0, st, f->PH,
                                (const float *)f->sproj, (const float *)a->de, (const float *)f->Fc, f->w_ee,
                                f->W_fe, f->lengths, a->dPH, part, L, B, T, A);
         else if (p3)
-            hipLaunchKernelGGL(phase2_mfma_kernel<false>, dim3(nt, B, cdiv(A, 16 * P3_NAT)), dim3(256), 0, st, f->PH,
+            hipLaunchKernelGGL(phase2_tile_kernel<false>, dim3(nt, B, cdiv(A, 16 * P3_NAT)), dim3(256), 0, st, f->PH,
                                (const float *)f->sproj, (const float *)a->de, (const float *)f->Fc, f->w_ee,
                                f->W_fe, f->lengths, a->dPH, part, L, B, T, A);
         else
