@@ -373,18 +373,26 @@ def config5_probe(dev, steps=5, warmup=2):
             "parameters": n_par, "loss": float(loss.detach())}
 
 
-def timed_steps(step, steps, warmup, sync_loss=False):
+def timed_steps(step, steps, warmup, sync_loss=False, ahead=2):
     """warmup untimed calls of step(), then `steps` timed ones: per-step durations (ms) from HIP events recorded on
     the current stream at every step boundary, and the wall clock of the whole region.  sync_loss: float(loss)
     after every step, the reference's `print(loss.item())` (train.py:69-73)."""
-    for _ in range(warmup):
+    wevs = []
+    for i in range(warmup):
+        if ahead and i >= ahead:
+            wevs[i - ahead].synchronize()
         step()
+        e = torch.cuda.Event()
+        e.record()
+        wevs.append(e)
     torch.cuda.synchronize()
     evs = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
     t0 = time.perf_counter()
     evs[0].record()
     loss = None
     for i in range(steps):
+        if ahead and i >= ahead:
+            evs[i + 1 - ahead].synchronize()      # at most `ahead` steps in flight (see main)
         loss = step()
         if sync_loss:
             float(loss)
@@ -632,6 +640,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--max-ahead", type=int, default=2,
+                    help="steps the host may run ahead of the device (0 = unbounded); see the comment at the warm-up loop")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-config5", action="store_true", help="skip the Conformer (config 5) side measurement")
     ap.add_argument("--no-config4", action="store_true", help="skip the CSJ-shape (config 4) side measurement")
@@ -733,8 +743,21 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # The host enqueues a step in 3-5 ms and would run up to K steps ahead of the device; every step in flight holds
+    # its own ~2 GB of activations in torch's caching allocator (a block is reusable only once the device has passed
+    # its last use), so an unbounded run-ahead keeps growing the pool with hipMalloc calls INSIDE the timed region
+    # (seen as 20-30 ms steps scattered over the first dozen).  As a training loop that looks at its loss does, the
+    # host stays at most `ahead` steps in front of the device: it waits for the end-of-step event of step i - ahead
+    # before it enqueues step i -- the device never idles (two steps are 34 ms of queued work).
+    ahead = max(0, args.max_ahead)
+    wevs = []
     for i in range(args.warmup):
+        if ahead and i >= ahead:
+            wevs[i - ahead].synchronize()
         step()
+        e = torch.cuda.Event()
+        e.record()
+        wevs.append(e)
         log(f'warm-up step {i} enqueued')
     barrier()
     log('warm-up done')
@@ -745,6 +768,8 @@ def main():
     evs[0].record()
     host_t = []
     for i in range(args.steps):
+        if ahead and i >= ahead:
+            evs[i + 1 - ahead].synchronize()      # the end of step i - ahead
         loss = step()
         evs[i + 1].record()
         host_t.append(time.perf_counter())
@@ -836,6 +861,7 @@ def main():
             "ms_per_step_mean": mean_ms, "value_from_mean": total_frames / (mean_ms * 1e-3),
             "ms_per_step_min_max": [min(step_ms), max(step_ms)],
             "ms_per_step_all": [round(v, 3) for v in step_ms],
+            "max_steps_in_flight": ahead,
             "host_enqueue_ms_all": [round((b - a) * 1e3, 3) for a, b in zip([t0] + host_t[:-1], host_t)],
             "ms_per_step_exact_f32": exact_ms,
             "value_exact_f32": (total_frames / (exact_ms * 1e-3)) if exact_ms else None,
