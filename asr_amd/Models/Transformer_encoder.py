@@ -19,7 +19,7 @@ import os
 import torch
 import torch.nn as nn
 
-from .. import _lib, ops
+from .. import _lib, ops, streams
 from .._lib import check
 
 KSIZE = 31      # Transformer_encoder.py:215
@@ -131,25 +131,27 @@ def _zeros_like_all(*ws):
     return out
 
 
-def _linear_bwd(dy2, x2, W2, bias=True, dx_out=None, accumulate=False, sums=None, dW=None):
-    """Returns (dx, dW, db) of y = x W^T + b; dx is written (or added) into dx_out when given.  With ``sums`` (a
-    list) the bias gradient is only queued there as (dy2, db): the caller sums all of a block's bias gradients
-    with one ops.colsum_multi call once the block's backward has produced them."""
-    if dW is None:
-        dW = torch.empty_like(W2)
-        ops.matmul_tn(dy2, x2, dW)
-    else:                                   # pre-zeroed by the caller (_zeros_like_all)
-        ops.matmul_tn(dy2, x2, dW, zeroed=True)
-    db = None
-    if bias:
-        db = _e(W2.shape[0], like=x2)
-        if sums is not None:
-            sums.append((dy2, db))
-        else:
-            ops.colsum(dy2, db)
-    dx = dx_out if dx_out is not None else _e(dy2.shape[0], W2.shape[1], like=x2)
+def _linear_dx(dy2, W2, dx_out=None, accumulate=False):
+    """dx of y = x W^T + b, written (or added) into dx_out when given: the part of a Linear's backward the next
+    kernel of the chain waits for."""
+    dx = dx_out if dx_out is not None else _e(dy2.shape[0], W2.shape[1], like=dy2)
     ops.matmul_nn(dy2, W2, dx, accumulate=accumulate)
-    return dx, dW, db
+    return dx
+
+
+def _linear_dw(pairs, bias_pairs):
+    """The part nothing downstream reads: dW = dy^T x for every (dy2, x2, W2) of ``pairs`` (split-K products into one
+    zero-filled buffer) and the column sums ``bias_pairs`` = [(dy2, width)] in one ops.colsum_multi call.  Called
+    inside a streams.on_side block by the blocks' backward functions, so that these products and sums overlap the
+    NEXT block's data-gradient chain (layer norm, activations, dropout masks: HBM-bound passes that leave the matrix
+    pipe idle).  Returns ([dW], [db])."""
+    dWs = _zeros_like_all(*[w for _, _, w in pairs])
+    for (dy2, x2, _), dW in zip(pairs, dWs):
+        ops.matmul_tn(dy2, x2, dW, zeroed=True)
+    dbs = [_e(n, like=dy2) for dy2, n in bias_pairs]
+    if dbs:
+        ops.colsum_multi([(dy2, db) for (dy2, _), db in zip(bias_pairs, dbs)])
+    return dWs, dbs
 
 
 def _drop(x, p, training, seed):
@@ -207,6 +209,7 @@ class _FFFunction(torch.autograd.Function):
         y, m_o, f = _residual_drop(x2, o, scale, p, training, n_out_drop)
         ctx.save_for_backward(x2, ln_w, w1, w2, mean, rstd, h, a, s)
         ctx.aux = (p, m1, m_o, f)
+        ctx.wparams = (w1, b1, w2, b2)
         return y.view_as(x)
 
     @staticmethod
@@ -216,16 +219,15 @@ class _FFFunction(torch.autograd.Function):
         x2, ln_w, w1, w2, mean, rstd, h, a, s = ctx.saved_tensors
         p, m1, m_o, f = ctx.aux
         dy2 = dy.contiguous().view_as(x2)
-        sums = []
-        zW1, zW2 = _zeros_like_all(w1, w2)
         do = _scale_mask(dy2, m_o, f)
-        ds, dW2, db2 = _linear_bwd(do, s, w2, sums=sums, dW=zW2)
+        ds = _linear_dx(do, w2)
         da = torch.empty_like(a)
         check(lib.asr_swish_bwd(ds.data_ptr(), a.data_ptr(), m1.data_ptr() if m1 is not None else 0, da.data_ptr(),
                                 a.numel(), C.c_float(p if m1 is not None else 0.0), _st()))
-        dh, dW1, db1 = _linear_bwd(da, h, w1, sums=sums, dW=zW1)
-        ops.colsum_multi(sums)
+        dh = _linear_dx(da, w1)
         dx, dg, dbeta = _ln_bwd(dh, x2, ln_w, mean, rstd, dy2)
+        with streams.on_side(dy2.device, do, s, da, h, params=ctx.wparams):
+            (dW2, dW1), (db2, db1) = _linear_dw([(do, s, w2), (da, h, w1)], [(do, w2.shape[0]), (da, w1.shape[0])])
         return dx.view_as(dy), dg, dbeta, dW1, db1, dW2, db2, None, None, None, None
 
 
@@ -278,6 +280,7 @@ class _RelAttnFunction(torch.autograd.Function):
         y, m_o, f_o = _residual_drop(x2, _linear(cx, wo, bo), 1.0, p, training, 1)
         ctx.save_for_backward(x2, nw, wq, wk, wv, wpos, wo, pe, keep, mean, rstd, h, qu, qv, k, vv, pp, attn, attn_d, cx)
         ctx.aux = (B, T, d, H, p, scale, m_att, m_o, f_o)
+        ctx.wparams = (wq, bq, wk, bk, wv, bv, wpos, u, v, wo, bo)
         return y.view_as(x)
 
     @staticmethod
@@ -290,10 +293,8 @@ class _RelAttnFunction(torch.autograd.Function):
         Tp = _pad4(T)
         proj, score, posp = (d, dk, T * d), (Tp, T * Tp, H * T * Tp), (d, dk, 0)
         dy2 = dy.contiguous().view_as(x2)
-        sums = []
-        zWo, zWq, zWk, zWv, zWpos = _zeros_like_all(wo, wq, wk, wv, wpos)
         do = _scale_mask(dy2, m_o, f_o)
-        dcx, dWo, dbo = _linear_bwd(do, cx, wo, sums=sums, dW=zWo)
+        dcx = _linear_dx(do, wo)
         dattn = _e(B, H, T, Tp, like=x2)
         _head_gemm(dcx, vv, dattn, T, T, dk, H, B, a=proj, b=proj, c=score)                       # d attn = d ctx v^T
         dvv = torch.empty_like(vv)
@@ -306,22 +307,21 @@ class _RelAttnFunction(torch.autograd.Function):
         _head_gemm(dattn, k, dqu, T, dk, T, H, B, a=score, b=proj, c=proj, b_mode=1)               # d ac k
         _head_gemm(dattn, qu, dkk, T, dk, T, H, B, a=score, b=proj, c=proj, a_mode=1, b_mode=1, pad_ok=1)    # d ac^T (q + u)
         _head_gemm(dbd, pp, dqv, T, dk, T, H, B, a=score, b=posp, c=proj, b_mode=1)                # d bd p
-        # d p[h] = sum_b d bd[b,h]^T (q + v)[b,:,h,:]: the reduction runs over (b, i) through a two-level row map
-        # (only heads x ceil(T/64) tiles: split the long reduction over workgroups, 464 -> 52 us at config 5)
-        sk = max(1, min(16, (B * T) // 512))
-        dpp = torch.zeros_like(pp) if sk > 1 else torch.empty_like(pp)
-        ops.sgemm(dbd, qv, dpp, T, dk, B * T, a_mode=1, b_mode=1, a_two=(T, Tp, H * T * Tp), b_stride=d, c_stride=d,
-                  nbatch=H, batch_a=T * Tp, batch_b=dk, batch_c=dk, pad_ok=1, splitk=sk)
-        du, dv = _e(d, like=x2), _e(d, like=x2)
-        sums += [(dqu, du), (dqv, dv)]
         dq = _axpby(dqu, dqv, 1.0, 1.0)
-        dh, dWq, dbq = _linear_bwd(dq, h, wq, sums=sums, dW=zWq)
-        _, dWk, dbk = _linear_bwd(dkk, h, wk, dx_out=dh, accumulate=True, sums=sums, dW=zWk)
-        _, dWv, dbv = _linear_bwd(dvv, h, wv, dx_out=dh, accumulate=True, sums=sums, dW=zWv)
-        ops.colsum_multi(sums)                                              # six bias gradients, two launches
-        dWpos = zWpos
-        ops.matmul_tn(dpp, pe, dWpos, zeroed=True)
+        dh = _linear_dx(dq, wq)
+        _linear_dx(dkk, wk, dx_out=dh, accumulate=True)
+        _linear_dx(dvv, wv, dx_out=dh, accumulate=True)
         dx, dg, dbeta = _ln_bwd(dh, x2, nw, mean, rstd, dy2)
+        with streams.on_side(dy2.device, do, cx, dq, dkk, dvv, h, dbd, qv, pe, dqu, dqv, params=ctx.wparams):
+            # d p[h] = sum_b d bd[b,h]^T (q + v)[b,:,h,:]: the reduction runs over (b, i) through a two-level row map
+            # (only heads x ceil(T/64) tiles: split the long reduction over workgroups, 464 -> 52 us at config 5)
+            sk = max(1, min(16, (B * T) // 512))
+            dpp = torch.zeros_like(pp) if sk > 1 else torch.empty_like(pp)
+            ops.sgemm(dbd, qv, dpp, T, dk, B * T, a_mode=1, b_mode=1, a_two=(T, Tp, H * T * Tp), b_stride=d, c_stride=d,
+                      nbatch=H, batch_a=T * Tp, batch_b=dk, batch_c=dk, pad_ok=1, splitk=sk)
+            (dWo, dWq, dWk, dWv, dWpos), (dbo, dbq, dbk, dbv, du, dv) = _linear_dw(
+                [(do, cx, wo), (dq, h, wq), (dkk, h, wk), (dvv, h, wv), (dpp, pe, wpos)],
+                [(do, d), (dq, d), (dkk, d), (dvv, d), (dqu, d), (dqv, d)])    # six column sums, two launches
         return (dx.view_as(dy), dg, dbeta, dWq, dbq, dWk, dbk, dWv, dbv, dWpos, du.view(H, dk), dv.view(H, dk), dWo, dbo,
                 None, None, None, None, None)
 
@@ -364,6 +364,7 @@ class _ConvModuleFunction(torch.autograd.Function):
         y, m_o, f_o = _residual_drop(x2, _linear(s, W2, pw2b), 1.0, p, training, 1)
         ctx.save_for_backward(x2, lnw, pw1w, dww, cow, bnw, bnb, pw2w, mean, rstd, h, a, g, c1, c2, msum, vsum, s)
         ctx.aux = (B, T, d, p, training, ms, vs, m_o, f_o)
+        ctx.wparams = (pw1w, pw1b, dww, dwb, cow, cob, pw2w, pw2b)
         return y.view_as(x)
 
     @staticmethod
@@ -375,10 +376,8 @@ class _ConvModuleFunction(torch.autograd.Function):
         rows = B * T
         W1, Wd, Wc, W2 = pw1w.view(2 * d, d), dww.view(d, KSIZE), cow.view(d, d), pw2w.view(d, d)
         dy2 = dy.contiguous().view_as(x2)
-        bias_sums = []
-        zW1, zWc, zW2 = _zeros_like_all(W1, Wc, W2)
         do = _scale_mask(dy2, m_o, f_o)
-        ds, dW2, db2 = _linear_bwd(do, s, W2, sums=bias_sums, dW=zW2)
+        ds = _linear_dx(do, W2)
         part = _e(int(lib.asr_bn_blocks(rows)), 2 * d, like=x2)
         check(lib.asr_bn_swish_bwd_part(ds.data_ptr(), c2.data_ptr(), msum.data_ptr(), vsum.data_ptr(), C.c_float(ms),
                                         C.c_float(vs), bnw.data_ptr(), bnb.data_ptr(), part.data_ptr(), rows, d, LN_EPS, _st()))
@@ -388,21 +387,21 @@ class _ConvModuleFunction(torch.autograd.Function):
         check(lib.asr_bn_swish_bwd(ds.data_ptr(), c2.data_ptr(), msum.data_ptr(), vsum.data_ptr(), C.c_float(ms),
                                    C.c_float(vs), bnw.data_ptr(), bnb.data_ptr(), sums.data_ptr() if training else 0,
                                    dc2.data_ptr(), rows, d, LN_EPS, _st()))
-        dc1, dWc, dbc = _linear_bwd(dc2, c1, Wc, sums=bias_sums, dW=zWc)
-        ddb = _e(d, like=x2)
-        bias_sums.append((dc1, ddb))
-        wpart = _e(int(lib.asr_dwconv_bwd_w_chunks(B, T)), KSIZE * d, like=x2)
-        check(lib.asr_dwconv_bwd_w(dc1.data_ptr(), g.data_ptr(), wpart.data_ptr(), B, T, d, KSIZE, _st()))
-        dwkc = _e(KSIZE, d, like=x2)
-        ops.colsum(wpart, dwkc.view(-1))
-        dWd = ops.transpose(dwkc)                                           # (K, d) -> (d, K)
+        dc1 = _linear_dx(dc2, Wc)
         dg = torch.empty_like(g)
         check(lib.asr_dwconv(dc1.data_ptr(), Wd.data_ptr(), 0, dg.data_ptr(), B, T, d, KSIZE, 1, _st()))
         da = torch.empty_like(a)
         check(lib.asr_glu_bwd(dg.data_ptr(), a.data_ptr(), da.data_ptr(), rows, d, _st()))
-        dh, dW1, db1 = _linear_bwd(da, h, W1, sums=bias_sums, dW=zW1)
-        ops.colsum_multi(bias_sums)
+        dh = _linear_dx(da, W1)
         dx, dgam, dbeta = _ln_bwd(dh, x2, lnw, mean, rstd, dy2)
+        with streams.on_side(dy2.device, do, s, dc2, c1, dc1, g, da, h, params=ctx.wparams):
+            wpart = _e(int(lib.asr_dwconv_bwd_w_chunks(B, T)), KSIZE * d, like=x2)
+            check(lib.asr_dwconv_bwd_w(dc1.data_ptr(), g.data_ptr(), wpart.data_ptr(), B, T, d, KSIZE, _st()))
+            dwkc = _e(KSIZE, d, like=x2)
+            ops.colsum(wpart, dwkc.view(-1))
+            dWd = ops.transpose(dwkc)                                       # (K, d) -> (d, K)
+            (dW2, dWc, dW1), (db2, dbc, ddb, db1) = _linear_dw(
+                [(do, s, W2), (dc2, c1, Wc), (da, h, W1)], [(do, d), (dc2, d), (dc1, d), (da, 2 * d)])
         return (dx.view_as(dy), dgam, dbeta, dW1.view_as(pw1w), db1, dWd.view_as(dww), ddb, dWc.view_as(cow), dbc,
                 sums[d:], sums[:d], dW2.view_as(pw2w), db2, None, None, None, None)
 
@@ -436,6 +435,7 @@ class _CnnEmbeddingFunction(torch.autograd.Function):
         out = _linear(y2.view(B * T2, F2 * Cc), woutp)
         ctx.save_for_backward(col1, y1, col2, y2, w2p, woutp)
         ctx.dims = (B, T1, F1, T2, F2, Cc)
+        ctx.wparams = (w1, b1, w2, b2, wout)
         return out.view(B, T2, -1)
 
     @staticmethod
@@ -445,12 +445,16 @@ class _CnnEmbeddingFunction(torch.autograd.Function):
         col1, y1, col2, y2, w2p, woutp = ctx.saved_tensors
         B, T1, F1, T2, F2, Cc = ctx.dims
         do = dout.contiguous().view(B * T2, -1)
-        dy2, dwoutp, _ = _linear_bwd(do, y2.view(B * T2, F2 * Cc), woutp, bias=False)
-        dwout = ops.transpose(dwoutp.view(-1, F2, Cc)).view(-1, Cc * F2)
+        y2f = y2.view(B * T2, F2 * Cc)
+        dy2 = _linear_dx(do, woutp)
         dpre2 = torch.empty_like(y2)
         check(lib.asr_relu_bwd(dy2.data_ptr(), y2.data_ptr(), dpre2.data_ptr(), y2.numel(), _st()))
-        dcol2, dw2p, db2 = _linear_bwd(dpre2, col2, w2p)
-        dw2 = ops.transpose(dw2p.view(Cc, 9, Cc)).view(Cc, Cc, 3, 3)
+        # the two large weight gradients run beside the data gradient of the second convolution and its col2im
+        with streams.on_side(do.device, do, y2, dpre2, col2, params=ctx.wparams):
+            (dwoutp, dw2p), (db2,) = _linear_dw([(do, y2f, woutp), (dpre2, col2, w2p)], [(dpre2, Cc)])
+            dwout = ops.transpose(dwoutp.view(-1, F2, Cc)).view(-1, Cc * F2)
+            dw2 = ops.transpose(dw2p.view(Cc, 9, Cc)).view(Cc, Cc, 3, 3)
+        dcol2 = _linear_dx(dpre2, w2p)
         dpre1 = torch.empty_like(y1)                                        # col2im and the ReLU gradient in one pass
         check(lib.asr_col2im_3x3s2(dcol2.data_ptr(), y1.data_ptr(), dpre1.data_ptr(), B, T1, F1, Cc, _st()))
         dw1p = _e(Cc, 12, like=y1)

@@ -350,20 +350,14 @@ def config5_probe(dev, steps=5, warmup=2):
         loss.backward()
         return loss
 
-    # the side stream pays off under the BLSTM's latency-bound recurrences; this encoder is GEMM-bound and
-    # the decoder's weight gradients gain nothing from sharing CUs with it (88.6 ms off, 89.9 ms on)
+    # side stream on: since round 3 the Conformer blocks put their weight / bias gradients there too, beside the next
+    # block's data-gradient chain (56.4 -> 53.9 ms; with only the decoder's gradients there it gained nothing)
     from asr_amd import streams
     was = streams.ENABLED
-    streams.enable(False)
+    streams.enable(True)
     try:
-        for _ in range(warmup):
-            step()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(steps):
-            loss = step()
-        torch.cuda.synchronize()
-        ms = (time.perf_counter() - t0) / steps * 1e3
+        per, _, loss = timed_steps(step, steps, warmup)
+        ms = median(per)
     finally:
         streams.enable(was)
     n_par = sum(p.numel() for p in m.parameters())

@@ -400,3 +400,52 @@ def test_full_size_config5_properties():
             fds.append((vals[0] - vals[1]) / (2 * eps))
         fd = fds[1] + (fds[1] - fds[0]) / 3.0
     assert abs(fd - analytic) / max(abs(analytic), 1e-6) < 3e-2, (fds, fd, analytic)
+
+
+def test_weight_gradients_on_side_stream_match_one_stream():
+    """The blocks' weight / bias gradients run on the side stream when a stream-aware owner has enabled it
+    (asr_amd/streams.py; the bench's config-5 leg, BucketedGradReducer): same seeds, every gradient against the
+    one-stream pass (split-K products add with float atomics: equal to rounding, not bit for bit), three passes in a
+    row so that a block recycled under a pending side-stream read would show."""
+    from asr_amd import streams
+    from asr_amd.Loss.label_smoothing import label_smoothing_loss
+    from asr_amd.Models.AttModel import AttModel
+    from oracle import ref_model as R
+    dev = _dev()
+    hp = R.make_hp(lmfb_dim=40, frame_stacking=1, num_hidden_nodes_encoder=256, num_hidden_nodes_decoder=32,
+                   num_classes=50, encoder_type="Conformer", encoder_dropout=0.1)
+    torch.manual_seed(11)
+    m = AttModel(hp)
+    m.encoder.encoder.layers = torch.nn.Sequential(*list(m.encoder.encoder.layers)[:3])
+    m = m.to(dev).train()
+    B, T, L = 4, 300, 12
+    lens = torch.tensor([300, 251, 212, 180])
+    x = torch.randn(B, T, 40)
+    src_pos = torch.zeros(B, T, dtype=torch.int64)
+    for b, n in enumerate(lens.tolist()):
+        x[b, n:] = 0
+        src_pos[b, :n] = torch.arange(1, n + 1)
+    tl = torch.tensor([12, 9, 7, 5])
+    tgt = torch.randint(1, 50, (B, L))
+    x, src_pos, tgt, tl = x.to(dev), src_pos.to(dev), tgt.to(dev), tl.to(dev)
+
+    def grads(side):
+        streams.enable(side)
+        torch.manual_seed(7)                      # the dropout seeds come from torch's generator
+        m.zero_grad(set_to_none=True)
+        loss = label_smoothing_loss(m(x, lens, tgt, src_pos), tgt, tl)
+        loss.backward()
+        torch.cuda.synchronize()
+        return float(loss), {n: p.grad.clone() for n, p in m.named_parameters()}
+
+    was = streams.ENABLED
+    try:
+        l0, g0 = grads(False)
+        for _ in range(3):
+            l1, g1 = grads(True)
+            assert l1 == l0
+            for n in g0:
+                assert torch.isfinite(g1[n]).all(), n
+                assert float((g1[n] - g0[n]).abs().max()) <= 1e-5 * float(g0[n].abs().max()) + 1e-12, n
+    finally:
+        streams.enable(was)

@@ -33,7 +33,7 @@ tgt = torch.randint(0, V, (B, L), generator=g)
 for b in range(B):
     tgt[b, tl[b]:] = 0
 tgt, tl_d = tgt.to(dev), tl.to(dev)
-if os.environ.get("ASR_SIDE_STREAM", "0") != "0":
+if os.environ.get("ASR_SIDE_STREAM", "1") != "0":      # weight / bias gradients beside the data-gradient chain
     streams.enable(True)
 
 
