@@ -52,14 +52,10 @@ def enc_step():
 
 
 def timed(fn, warm, n):
-    for _ in range(warm):
-        fn()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(n):
-        out = fn()
-    torch.cuda.synchronize()
-    return (time.perf_counter() - t0) / n * 1e3, out
+    """Median of per-step HIP-event times, the host at most two steps ahead of the device (bench.py::timed_steps)."""
+    from bench import timed_steps, median
+    per, _, out = timed_steps(fn, n, warm)
+    return median(per), out
 
 
 n = int(os.environ.get("CONF_STEPS", "10"))
