@@ -3,7 +3,7 @@ HIPCC ?= /opt/rocm/bin/hipcc
 ARCH ?= gfx950
 SRC := $(wildcard asr_amd/csrc/*.hip)
 OBJ := $(patsubst asr_amd/csrc/%.hip,build/%.o,$(SRC))
-HDR := $(wildcard asr_amd/csrc/*.cuh) include/asr_amd.h
+HDR := $(wildcard asr_amd/csrc/*.h) include/asr_amd.h
 LIB := asr_amd/lib/libasr_amd.so
 CXXFLAGS := -O3 -std=c++17 -fPIC --offload-arch=$(ARCH) -Wall -Wno-unused-function -Wno-pass-failed -Wno-bitwise-instead-of-logical
 

@@ -24,7 +24,7 @@
 #include <string.h>
 #include <algorithm>
 
-#include "tile16.cuh"
+#include "tile16.h"
 
 #define NCH 10     // conv channels  (Models/attention.py:22)
 #define KW 100     // conv taps
@@ -754,7 +754,7 @@ static bool al16(const void *p) { return (((uintptr_t)p) & 15) == 0; }
 #define PD_HF_MAX 22       // ... of the forward instantiation for long utterances (T = 800: 39 frame groups x 21)
 #define PD_AL (32 * PD_MTP)   // attention units the LDS tables are padded to (zeros past A)
 #define PD_KF 5            // float4 per lane of a job's K slot: K <= 32 slots x 20 = 640
-// in-launch waits are bounded by wall time: asr_wait_expired (common.cuh), 4 s on the 100 MHz counter
+// in-launch waits are bounded by wall time: asr_wait_expired (common.h), 4 s on the 100 MHz counter
 #define PD_OOB 0x7ffffff0
 typedef unsigned int pd_u32x4 __attribute__((ext_vector_type(4)));
 

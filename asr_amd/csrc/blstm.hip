@@ -17,7 +17,7 @@
 // plus h_{t-1}; the step is latency-bound, not bandwidth-bound.
 #include <string.h>
 
-#include "tile16.cuh"
+#include "tile16.h"
 
 __global__ __launch_bounds__(256) void blstm_fwd_step_kernel(
     const float *__restrict__ W_hh, float *__restrict__ G, float *__restrict__ Cs,
@@ -185,7 +185,7 @@ static int blstm_bwd_steps(const float *W_hhT, float *G, const float *Cs, const 
 // budget sets *err and makes the workgroup leave; the others then time out the
 // same way, so the grid always drains.
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-// in-launch waits are bounded by wall time: asr_wait_expired (common.cuh), 4 s on the 100 MHz counter
+// in-launch waits are bounded by wall time: asr_wait_expired (common.h), 4 s on the 100 MHz counter
 #define BLSTM_FLAG_WORDS_ 1024   // = BLSTM_FLAG_WORDS (defined with the host dispatch)
 #define BLSTM_PACE_START 8     // initial wait before a step's first exchange gather, units of s_sleep 2
 #define BLSTM_PACE_MAX 40

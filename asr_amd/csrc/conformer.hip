@@ -7,7 +7,7 @@
 // encoder output: every kernel here is coalesced along C, and the reference's transposes to
 // (B, C, T) around its Conv1d / BatchNorm1d calls (:230,237) disappear.  All of these kernels
 // are HBM-bound passes (bytes per launch in DESIGN.md 3.6).
-#include "common.cuh"
+#include "common.h"
 
 #define GRID1D(n) ((int)(((n) + 255) / 256 > 8192 ? 8192 : ((n) + 255) / 256))
 #define FOR_EACH(i, n) \

@@ -20,7 +20,7 @@
 //                         subtracted.  Repeated labels are summed by ONE thread per distinct label along a
 //                         chain built once per utterance, blanks by a fixed-order tree: no float
 //                         atomics, bitwise reproducible.
-#include "common.cuh"
+#include "common.h"
 
 #define CTC_T 256
 

@@ -12,7 +12,7 @@
 // HBM-bound: the raw batch is read twice (sums, apply) and the stacked batch written once.
 // The mask positions come from the host (the reference draws them with Python's `random`;
 // asr_amd/utils/features.py replays the same sequence of randrange calls).
-#include "common.cuh"
+#include "common.h"
 
 #define FEAT_CH 64   // frames per partial-sum chunk
 

@@ -16,7 +16,7 @@
 #include <stdlib.h>
 #include <string.h>
 
-#include "common.cuh"
+#include "common.h"
 
 #define ASR_GEMM_PRECISION_DEFAULT 1
 

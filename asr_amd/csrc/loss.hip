@@ -9,7 +9,7 @@
 //   loss_row = -(1-eps) lp_y - eps/(V-1) (sum_v z_v - V lse - lp_y)
 //   dz_v     = w (softmax(z)_v - q_v),  q_y = 1-eps, q_v = eps/(V-1) otherwise
 //   w        = 1/t_i (T_norm) [/B (B_norm)] for l < t_i, else 0
-#include "common.cuh"
+#include "common.h"
 
 #define LS_THREADS 256
 

@@ -2,7 +2,7 @@
 #include <stdarg.h>
 #include <string.h>
 
-#include "common.cuh"
+#include "common.h"
 
 static thread_local char g_err[512] = "";
 

@@ -4,7 +4,7 @@
 // torch.optim.Adam(lr, weight_decay=1e-5).step()).  Two launches for the norm (deterministic
 // two-stage sum), one for the update of all tensors; no host synchronisation anywhere --
 // the clip coefficient stays on the device.  HBM-bound: 8 floats of traffic per parameter.
-#include "common.cuh"
+#include "common.h"
 
 #define OPT_BLOCKS 32   // workgroups per tensor
 

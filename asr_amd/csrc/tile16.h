@@ -15,7 +15,7 @@
 // and no LDS staging (the operands are used once per workgroup).  The waves'
 // partial tiles are summed through LDS.
 #pragma once
-#include "common.cuh"
+#include "common.h"
 
 #define T16_MAXW 16
 
