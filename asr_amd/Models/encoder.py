@@ -92,6 +92,7 @@ PIPE_BWD = os.environ.get("ASR_PIPE_BWD", "1") != "0"
 # over the separate forward / reverse parameter tensors); ASR_MERGE_DIRECTIONS=0 restores two.
 MERGE_DIRECTIONS = os.environ.get("ASR_MERGE_DIRECTIONS", "1") != "0"
 PACK_WEIGHTS = os.environ.get("ASR_PACK_WEIGHTS", "1") != "0"     # pre-split W_ih for the projection / dX products (A/B timing)
+PACK_INPUT = os.environ.get("ASR_PACK_INPUT", "1") != "0"         # ... and the dropped-out layer input (projection, dW_ih)
 ROW_LIST_MIN_PADDING = float(os.environ.get("ASR_ROW_LIST_MIN_PADDING", "0.04"))
 
 
@@ -162,13 +163,28 @@ class _BLSTMLayerFunction(torch.autograd.Function):
         lib = _lib.load()
         inp = inp.contiguous()
         in_keep, in_scale = None, 1.0
+        inp_packed = False
         if in_drop is not None and in_drop[0] > 0.0:
             raw = inp
-            inp = torch.empty_like(raw)
-            in_keep = torch.empty(raw.numel(), device=raw.device, dtype=torch.uint8)
             in_scale = 1.0 / (1.0 - in_drop[0])
-            check(lib.asr_dropout_fwd(raw.data_ptr(), inp.data_ptr(), in_keep.data_ptr(), raw.numel(),
-                                      C.c_float(in_drop[0]), C.c_uint64(in_drop[1]), _stream()))
+            # The dropped-out input feeds two matrix products and nothing else (this layer's input projection, and its
+            # dW_ih in the backward): where asr_sgemm has pre-split kernels for both, the dropout writes {hi:lo} words
+            # instead of fp32 -- the same bytes, and neither product splits the operand again (bit-identical results)
+            Tn, Bn, Dn = raw.shape
+            n_rows = rl.n if rl is not None else Tn * Bn
+            k_dw = n_rows
+            inp_packed = (PACK_INPUT and PACK_WEIGHTS and MERGE_DIRECTIONS and not first and pre is None and nxt is None
+                          and ops.packed_ok(n_rows, 8 * H)
+                          and ops.packed_dw_ok(8 * H, Dn, k_dw, ops.pick_splitk(8 * H, Dn, k_dw))
+                          and None not in (ops.elem_delta(w_ih_f, w_ih_r), ops.elem_delta(b_ih_f, b_ih_r),
+                                           ops.elem_delta(b_hh_f, b_hh_r)))
+            if inp_packed:
+                inp, in_keep = ops.dropout_fwd_packed(raw, in_drop[0], in_drop[1])
+            else:
+                inp = torch.empty_like(raw)
+                in_keep = torch.empty(raw.numel(), device=raw.device, dtype=torch.uint8)
+                check(lib.asr_dropout_fwd(raw.data_ptr(), inp.data_ptr(), in_keep.data_ptr(), raw.numel(),
+                                          C.c_float(in_drop[0]), C.c_uint64(in_drop[1]), _stream()))
         if first:
             B, T, D = inp.shape
             in_two = (B, T * D, D)         # row (t*B + b) of the GEMM <-> inp[b, t]
@@ -198,7 +214,7 @@ class _BLSTMLayerFunction(torch.autograd.Function):
                     w_pk = ops.pack_hilo(w_ih_f, w_ih_r)
                 ops.sgemm(inp, w_ih_f, G, nrows, 8 * H, D, a_two=in_two, b_two=(4 * H, D, dw), c_stride=8 * H,
                           bias1=b_ih_f, bias2=b_hh_f, bias_two=(4 * H, db1, db2), m_idx=rows,
-                          b_pk=None if w_pk is None else (w_pk, D))
+                          b_pk=None if w_pk is None else (w_pk, D), a_packed=inp_packed)
             else:
                 for d, (w_ih, b_ih, b_hh) in enumerate(((w_ih_f, b_ih_f, b_hh_f), (w_ih_r, b_ih_r, b_hh_r))):
                     ops.sgemm(inp, w_ih, G, nrows, 4 * H, D, a_two=in_two, b_stride=D, c_stride=8 * H,
@@ -255,6 +271,7 @@ class _BLSTMLayerFunction(torch.autograd.Function):
             nxt.G = G_n
         ctx.save_for_backward(inp, G, Cs, Hout, lengths_dev, w_ih_f, w_hh_f, w_ih_r, w_hh_r)
         ctx.w_pk = w_pk
+        ctx.inp_packed = inp_packed
         ctx.W_hh = W_hh            # a copy of the weights as they are now: the backward reads it instead of concatenating again
         ctx.mask = mask
         ctx.wparams = (w_ih_f, w_hh_f, b_ih_f, b_hh_f, w_ih_r, w_hh_r, b_ih_r, b_hh_r)
@@ -386,7 +403,7 @@ class _BLSTMLayerFunction(torch.autograd.Function):
             if sk > 1:
                 gWi.zero_()
             ops.sgemm(dG, inp, gWi, 8 * H, D, K, a_mode=1, a_stride=8 * H, b_mode=1, b_two=in_two, c_stride=D,
-                      splitk=sk, k_idx=kl)
+                      splitk=sk, k_idx=kl, b_packed=ctx.inp_packed)
             gW_hh = None if split_streams else [grad_w_hh(d) for d in range(2)]
             db2 = db.clone()       # b_hh's copy (the clone reads db: it belongs on the stream that wrote it)
         if split_streams:          # enqueued AFTER the side block: its entry event must not wait for these two

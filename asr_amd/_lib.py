@@ -105,6 +105,7 @@ SYMBOLS = {
     "asr_grad_sqnorm": (C.c_int, [C.POINTER(TensorList), c_f, C.c_int, c_f, c_f]),
     "asr_clip_adam_step": (C.c_int, [C.POINTER(TensorList)] * 4 + [c_f] + [C.c_double] * 6 + [c_i64, c_f]),
     "asr_pack_hilo": (C.c_int, [c_f, c_f, c_i64, c_f, c_f]),
+    "asr_dropout_fwd_packed": (C.c_int, [c_f, c_f, c_f, c_i64, C.c_float, C.c_uint64, c_f]),
     "asr_blstm_ws_floats": (c_i64, [C.c_int, C.c_int]),
     "asr_blstm_precision": (C.c_int, [C.c_int]),
     "asr_blstm_xcd_groups": (C.c_int, [C.c_int]),

@@ -676,6 +676,31 @@ extern "C" int asr_pack_hilo(const float *src0, const float *src1, int64_t n, fl
     return ASR_OK;
 }
 
+// asr_dropout_fwd (misc.hip: same keep decision per element index, same scaled value) whose output leaves as {hi:lo}
+// words: the inter-layer dropout of the encoder feeds only matrix products, which then read it pre-split
+__global__ __launch_bounds__(256) void dropout_pack_kernel(const float *__restrict__ x, unsigned *__restrict__ y,
+                                                           uint8_t *__restrict__ mask, int64_t n, uint32_t thresh,
+                                                           float scale, uint64_t seed) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const bool keep = asr_keep(seed, i, thresh);
+        mask[i] = keep;
+        unsigned hi, lo;
+        bf_split(keep ? x[i] * scale : 0.f, 0.f, hi, lo);
+        y[i] = (hi << 16) | (lo & 0xffffu);
+    }
+}
+extern "C" int asr_dropout_fwd_packed(const float *x, float *y_packed, uint8_t *mask, int64_t n, float p, uint64_t seed,
+                                      void *stream) {
+    ASR_CHECK_ARG(x && y_packed && mask && n >= 0 && p >= 0.f && p < 1.f, "dropout_fwd_packed: bad argument");
+    if (n == 0) return ASR_OK;
+    const uint32_t thresh = (uint32_t)((double)p * 4294967296.0);
+    const int blocks = (int)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256);
+    hipLaunchKernelGGL(dropout_pack_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x,
+                       reinterpret_cast<unsigned *>(y_packed), mask, n, thresh, 1.0f / (1.0f - p), seed);
+    ASR_CHECK_LAUNCH("dropout_pack_kernel");
+    return ASR_OK;
+}
+
 extern "C" int asr_sgemm(const asr_gemm_desc *din, void *stream) {
     ASR_CHECK_ARG(din != nullptr, "sgemm: null descriptor");
     asr_gemm_desc d = *din;
@@ -765,8 +790,13 @@ extern "C" int asr_sgemm(const asr_gemm_desc *din, void *stream) {
         // pre-split operands: only where a kernel is instantiated for them (128 x 128 tiles, buffer loads on both
         // operands, bf16x3, A k-contiguous); the caller (asr_amd/ops.py) asks asr_sgemm_packed_ok first
         const int pk = (din->a_packed ? 1 : 0) | (din->b_packed ? 2 : 0);
-        ASR_CHECK_ARG(pk == 0 || (prec == 1 && buf_a && buf_b && d.a_mode == 0 && !d.k_idx && pk != 1 && (pk == 2 || d.b_mode == 0) &&
-                                  d.M >= 128 && d.N >= 128 && (t128 >= 320 || (sk > 1 && t128 >= 256)) && bf_tile == 0),
+        const bool pk_tiles = prec == 1 && d.M >= 128 && d.N >= 128 && (t128 >= 320 || (sk > 1 && t128 >= 256)) && bf_tile == 0;
+        // (i) A k-contiguous, buffer loads on both operands: B packed, or both (then B k-contiguous too);
+        // (ii) a weight-gradient product (both operands row-contiguous) whose B operand -- the layer's input -- is
+        //      packed: with a k list (pointer loaders) or with buffer loads on both
+        ASR_CHECK_ARG(pk == 0 ||
+                      (pk_tiles && buf_a && buf_b && d.a_mode == 0 && !d.k_idx && pk != 1 && (pk == 2 || d.b_mode == 0)) ||
+                      (pk_tiles && pk == 2 && d.a_mode == 1 && d.b_mode == 1 && (d.k_idx || (buf_a && buf_b))),
                       "sgemm: a_packed / b_packed set for a shape or mode without a pre-split kernel");
         // 128 x 128 tiles from 320 of them on (measured down to 375: tools/gemm_tile_pick.py; at 188 the 64 x 64 tile wins);
         // split-K launches sized for one resident round (asr_amd/ops.py pick_splitk) keep them from 256 on
@@ -778,6 +808,10 @@ extern "C" int asr_sgemm(const asr_gemm_desc *din, void *stream) {
         hipLaunchKernelGGL((sgemm_bf3_kernel<128, 128, 0, BM2, 3, false, true, true, 2>), grid, dim3(256), 0, st, d, perb, kflags); \
     else if (pk == 3 && BM_ == 128 && BN_ == 128 && AM == 0 && BM2 == 0 && NP == 3 && !KL)                            \
         hipLaunchKernelGGL((sgemm_bf3_kernel<128, 128, 0, 0, 3, false, true, true, 3>), grid, dim3(256), 0, st, d, perb, kflags); \
+    else if (pk == 2 && BM_ == 128 && BN_ == 128 && AM == 1 && BM2 == 1 && NP == 3 && KL)                             \
+        hipLaunchKernelGGL((sgemm_bf3_kernel<128, 128, 1, 1, 3, true, false, false, 2>), grid, dim3(256), 0, st, d, perb, kflags); \
+    else if (pk == 2 && BM_ == 128 && BN_ == 128 && AM == 1 && BM2 == 1 && NP == 3 && !KL)                            \
+        hipLaunchKernelGGL((sgemm_bf3_kernel<128, 128, 1, 1, 3, false, true, true, 2>), grid, dim3(256), 0, st, d, perb, kflags); \
     else if (buf_a && buf_b && !KL && NP == 3)                                                                        \
         hipLaunchKernelGGL((sgemm_bf3_kernel<BM_, BN_, AM, BM2, NP, false, true, true>), grid, dim3(256), 0, st, d, perb, kflags); \
     else if (buf_a && !KL && NP == 3)                                                                                 \
@@ -808,6 +842,7 @@ extern "C" int asr_sgemm(const asr_gemm_desc *din, void *stream) {
         ASR_CHECK_LAUNCH("sgemm_bf3_kernel");
         return ASR_OK;
     }
+    ASR_CHECK_ARG(!din->a_packed && !din->b_packed, "sgemm: pre-split operands need the bf16x3 fast path (precision mode, alignment, K >= 32)");
 #define LAUNCH(BM_, BN_, GK_, AM, BM2, F)                                                              \
     hipLaunchKernelGGL((sgemm_kernel<BM_, BN_, GK_, AM, BM2, F>), grid, dim3(256), 0, st, d, vecA, vecB, per)
 #define LAUNCH_KLIST(BM_, BN_, GK_, F)                                                                 \

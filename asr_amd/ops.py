@@ -100,12 +100,14 @@ def sgemm(A, B, Cm, M, N, K, *, a_mode=0, b_mode=0, a_stride=None, b_stride=None
                      nbatch, batch_a, bd, ba1, m_idx is not None or (k_idx is not None and a_mode == 1))
     d.b_span = _span(B, b_off, N if b_mode == 0 else K, K if b_mode == 0 else N, d.b_d, d.b_s0, d.b_s1,
                      nbatch, batch_b, bd, bb1, k_idx is not None and b_mode == 1)
-    if (b_pk is not None and not a_packed and a_mode == 0 and k_idx is None and nbatch == 1 and splitk == 1
-            and d.a_span > 0 and d.a_span < 0x7ffffff0 and packed_ok(M, N)):
+    if (b_pk is not None and (not a_packed or b_mode == 0) and a_mode == 0 and k_idx is None and nbatch == 1
+            and splitk == 1 and d.a_span > 0 and d.a_span < 0x7ffffff0 and packed_ok(M, N)):
         Bp, bps = b_pk
         span = _span(Bp, 0, N if b_mode == 0 else K, K if b_mode == 0 else N, 0, bps, 0, 1, 0, 0, 0, False)
         if span > 0 and span < 0x7ffffff0 and (b_mode == 0 or K * bps * 4 < 0x7ffffff0):
             d.B, d.b_d, d.b_s0, d.b_s1, d.b_span, d.b_packed = Bp.data_ptr(), 0, bps, 0, span, 1
+    if a_packed and not d.b_packed:
+        raise RuntimeError("asr_amd.ops.sgemm: a pre-split A operand needs a pre-split B (b_pk) at a shape packed_ok accepts")
     for name, idx, n in (("m_idx", m_idx, M), ("k_idx", k_idx, K)):
         if idx is None:
             setattr(d, name, 0)
@@ -126,6 +128,26 @@ def packed_ok(M, N):
     return (_lib.load().asr_gemm_precision(-1) == 1 and M >= 128 and N >= 128
             and ((M + 127) // 128) * ((N + 127) // 128) >= 320 and not os.environ.get("ASR_GEMM_BF_TILE")
             and os.environ.get("ASR_GEMM_BUF", "1") != "0" and os.environ.get("ASR_GEMM_PACKED", "1") != "0")
+
+
+def packed_dw_ok(M, N, K, splitk):
+    """True when asr_sgemm has a kernel for a weight-gradient product (a_mode 1, b_mode 1) whose B operand is
+    pre-split: bf16x3, 128 x 128 tiles (asr_sgemm picks them from 320 tiles x splits on, from 256 when K is split)."""
+    import os
+    tiles = ((M + 127) // 128) * ((N + 127) // 128) * max(1, min(splitk, (K + 31) // 32))
+    return (_lib.load().asr_gemm_precision(-1) == 1 and M >= 128 and N >= 128 and K >= 32
+            and (tiles >= 320 or (splitk > 1 and tiles >= 256)) and not os.environ.get("ASR_GEMM_BF_TILE")
+            and os.environ.get("ASR_GEMM_BUF", "1") != "0" and os.environ.get("ASR_GEMM_PACKED", "1") != "0")
+
+
+def dropout_fwd_packed(x, p, seed):
+    """Inverted dropout of x with the output as {hi:lo} words (in a float32 tensor of x's shape) and the uint8 keep mask:
+    asr_dropout_fwd's mask and values for the same p and seed, pre-split for asr_sgemm (a_packed / b_packed)."""
+    x = _req(x).contiguous()
+    y = torch.empty_like(x)
+    mask = torch.empty(x.numel(), device=x.device, dtype=torch.uint8)
+    check(_lib.load().asr_dropout_fwd_packed(_p(x), _p(y), _p(mask), x.numel(), C.c_float(p), C.c_uint64(seed), _stream()))
+    return y, mask
 
 
 def pack_hilo(src0, src1=None):

@@ -158,8 +158,10 @@ typedef struct {
     int64_t a_span, b_span;
     /* != 0: the operand holds pre-split elements, one 32-bit word {bf16 hi : bf16 lo} each (asr_pack_hilo) instead of
      * fp32 -- the bf16x3 split done once by a producer instead of by every tile that reads the element.  Only with
-     * asr_gemm_precision 1, a_mode 0, known spans, 128 x 128 tiles (>= 320 of them) and b_packed alone or both
-     * (a_packed alone has no kernel): anything else is rejected, ask asr_amd/ops.py::packed_ok.  Bit-identical results. */
+     * asr_gemm_precision 1 and 128 x 128 tiles (>= 320 of them, or >= 256 with splitk > 1), and either a_mode 0 with known
+     * spans and b_packed alone or both (a_packed alone has no kernel), or a_mode 1 / b_mode 1 (a weight gradient) with
+     * b_packed and a k list or known spans: anything else is rejected, ask asr_amd/ops.py::packed_ok / packed_dw_ok.
+     * Bit-identical results. */
     int a_packed, b_packed;
 } asr_gemm_desc;
 
@@ -178,6 +180,11 @@ int asr_gemm_precision(int mode);
  * the pre-split form asr_gemm_desc.a_packed / b_packed reads; two sources so that the forward and the reverse
  * direction's weight_ih of an nn.LSTM layer (Models/encoder.py:25) land in one contiguous [2][4H][D] operand. */
 int asr_pack_hilo(const float *src0, const float *src1, int64_t n, float *dst, void *stream);
+/* asr_dropout_fwd (below: the same mask and values for the same p and seed) whose output is written as {hi:lo} words:
+ * the dropout between two nn.LSTM layers (Models/encoder.py:26) feeds only matrix products -- the next layer's input
+ * projection (a_packed) and, in the backward, its dW_ih (b_packed) -- which then read it without splitting again. */
+int asr_dropout_fwd_packed(const float *x, float *y_packed, uint8_t *mask, int64_t n, float p, uint64_t seed,
+                           void *stream);
 
 /* small helpers used by the backward passes (bias gradients, layouts) */
 /* out[n] (+)= sum_m A[rowoff(m) + n]; accumulate != 0 keeps the old value.

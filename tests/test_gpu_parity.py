@@ -119,6 +119,89 @@ def test_sgemm_row_lists(R, N, K, keep, gemm_mode):
         ops.sgemm(Xd, Wd, out, n, N, K, a_stride=K, b_stride=K, c_stride=N, k_idx=idx)
 
 
+def test_dropout_packed_output_and_presplit_weight_gradient():
+    """asr_dropout_fwd_packed writes asr_dropout_fwd's mask and values as {hi:lo} words (bit for bit what asr_pack_hilo
+    makes of the fp32 output), and the weight-gradient product dW = dG^T X reads X in that form (b_packed) -- with the
+    k list of a ragged batch (pointer loaders) and without (buffer loads) -- giving the fp32-operand product's result
+    up to the order of the split-K atomics; as the A operand of the input projection it is bit-identical."""
+    from asr_amd import _lib, ops
+    import ctypes as C
+    lib = _lib.load()
+    dev = _dev()
+    T, B, D, H8 = 400, 32, 640, 2560
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(T, B, D, generator=g).to(dev)
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    y = torch.empty_like(x)
+    m = torch.empty(x.numel(), device=dev, dtype=torch.uint8)
+    assert lib.asr_dropout_fwd(x.data_ptr(), y.data_ptr(), m.data_ptr(), x.numel(), C.c_float(0.2), C.c_uint64(99), st) == 0
+    yp, mp = ops.dropout_fwd_packed(x, 0.2, 99)
+    assert torch.equal(m, mp)
+    assert torch.equal(yp.view(torch.int32), ops.pack_hilo(y).view_as(y).view(torch.int32))
+    dG = torch.randn(T * B, H8, generator=g).to(dev)
+    rows = torch.arange(0, T * B, dtype=torch.int32)[torch.rand(T * B, generator=g) < 0.8].to(dev)
+    X2, Xp2 = y.view(T * B, D), yp.view(T * B, D)
+    for kl, K in ((rows, rows.numel()), (None, T * B)):
+        sk = ops.pick_splitk(H8, D, K)
+        assert sk > 1 and ops.packed_dw_ok(H8, D, K, sk)
+        outs = []
+        for Bm, pk in ((X2, False), (Xp2, True)):
+            out = torch.zeros(H8, D, device=dev)
+            ops.sgemm(dG, Bm, out, H8, D, K, a_mode=1, a_stride=H8, b_mode=1, b_stride=D, c_stride=D, splitk=sk,
+                      k_idx=kl, b_packed=pk)
+            outs.append(out)
+        scale = float(outs[0].abs().max())
+        assert float((outs[0] - outs[1]).abs().max()) <= 2e-6 * scale
+        sel = rows.long() if kl is not None else slice(None)
+        want = dG.double()[sel].t() @ X2.double()[sel]
+        assert rel_err(outs[1].cpu(), want.cpu()) < 2e-5
+    # as the A operand of the projection (with pre-split weights): bit for bit the fp32-operand product
+    W = torch.randn(H8, D, generator=g).to(dev)
+    Wp = ops.pack_hilo(W).view_as(W)
+    C1, C2 = torch.empty(T * B, H8, device=dev), torch.empty(T * B, H8, device=dev)
+    ops.sgemm(X2, W, C1, rows.numel(), H8, D, a_stride=D, b_stride=D, c_stride=H8, m_idx=rows)
+    ops.sgemm(Xp2, W, C2, rows.numel(), H8, D, a_stride=D, b_stride=D, c_stride=H8, m_idx=rows, b_pk=(Wp, D), a_packed=True)
+    assert torch.equal(C1[rows.long()], C2[rows.long()])
+    with pytest.raises(RuntimeError):          # a pre-split A alone has no kernel
+        ops.sgemm(Xp2, W, C2, T * B, H8, D, a_stride=D, b_stride=D, c_stride=H8, a_packed=True)
+
+
+def test_encoder_with_presplit_layer_inputs_matches_fp32_inputs():
+    """Encoder step at the config-2 widths with the inter-layer dropout written pre-split (default where asr_sgemm has
+    the kernels) against the same step with fp32 layer inputs: same dropout masks (same seed), bit-identical forward
+    (the projections split the same two bf16 either way), gradients equal up to the split-K atomics' order."""
+    from asr_amd.Models import encoder as E
+    from oracle import ref_model as R
+    dev = _dev()
+    hp = R.make_hp(lmfb_dim=80, frame_stacking=3, num_hidden_nodes=320, num_encoder_layer=3, encoder_dropout=0.2)
+    torch.manual_seed(12)
+    enc = E.Encoder(hp).to(dev).train()
+    B, T = 32, 420
+    lengths = torch.linspace(T, T * 3 // 5, B).long()
+    x = torch.randn(B, T, 240)
+    for b in range(B):
+        x[b, lengths[b]:] = 0
+    w = torch.randn(B, T, 640, device=dev)
+    outs = []
+    old = E.PACK_INPUT
+    try:
+        for flag in (False, True):
+            E.PACK_INPUT = flag
+            for q in enc.parameters():
+                q.grad = None
+            torch.manual_seed(77)
+            h = enc(x.to(dev), lengths)
+            (h * w).sum().backward()
+            torch.cuda.synchronize()
+            outs.append((h.detach().clone(), [q.grad.clone() for q in enc.parameters()]))
+    finally:
+        E.PACK_INPUT = old
+    assert torch.equal(outs[0][0], outs[1][0])
+    for a, b_ in zip(outs[0][1], outs[1][1]):
+        assert float((a - b_).abs().max()) <= 1e-5 * float(a.abs().max()) + 1e-12
+    assert not E.persistent_error_flags()
+
+
 @pytest.mark.parametrize("M,N,K,b_mode", [(12800, 2560, 640, 0), (12800, 640, 2560, 1), (56000, 128, 96, 0)])
 def test_sgemm_presplit_weights_bit_identical(M, N, K, b_mode):
     """asr_sgemm with the B operand handed over pre-split (asr_pack_hilo: one {bf16 hi : bf16 lo} word per element,
