@@ -276,7 +276,8 @@ class _RelAttnFunction(torch.autograd.Function):
                                           C.c_float(p if on else 0.0), C.c_uint64(seed), _st()))
         del bd
         cx = _e(B * T, d, like=x)
-        _head_gemm(attn_d, vv, cx, T, dk, T, H, B, a=score, b=proj, c=proj, b_mode=1)   # attn v   :136
+        # (the maps' padding columns are zero: pad_ok bit 2 lets K = T, not a multiple of 4, take the 16-byte path)
+        _head_gemm(attn_d, vv, cx, T, dk, T, H, B, a=score, b=proj, c=proj, b_mode=1, pad_ok=4)   # attn v   :136
         y, m_o, f_o = _residual_drop(x2, _linear(cx, wo, bo), 1.0, p, training, 1)
         ctx.save_for_backward(x2, nw, wq, wk, wv, wpos, wo, pe, keep, mean, rstd, h, qu, qv, k, vv, pp, attn, attn_d, cx)
         ctx.aux = (B, T, d, H, p, scale, m_att, m_o, f_o)
@@ -304,9 +305,9 @@ class _RelAttnFunction(torch.autograd.Function):
                                           C.c_float(scale), B, H, T, Tp, m_att.data_ptr() if m_att is not None else 0,
                                           C.c_float(p if m_att is not None else 0.0), _st()))
         dqu, dkk, dqv = torch.empty_like(qu), torch.empty_like(k), torch.empty_like(qv)
-        _head_gemm(dattn, k, dqu, T, dk, T, H, B, a=score, b=proj, c=proj, b_mode=1)               # d ac k
+        _head_gemm(dattn, k, dqu, T, dk, T, H, B, a=score, b=proj, c=proj, b_mode=1, pad_ok=4)     # d ac k
         _head_gemm(dattn, qu, dkk, T, dk, T, H, B, a=score, b=proj, c=proj, a_mode=1, b_mode=1, pad_ok=1)    # d ac^T (q + u)
-        _head_gemm(dbd, pp, dqv, T, dk, T, H, B, a=score, b=posp, c=proj, b_mode=1)                # d bd p
+        _head_gemm(dbd, pp, dqv, T, dk, T, H, B, a=score, b=posp, c=proj, b_mode=1, pad_ok=4)      # d bd p
         dq = _axpby(dqu, dqv, 1.0, 1.0)
         dh = _linear_dx(dq, wq)
         _linear_dx(dkk, wk, dx_out=dh, accumulate=True)

@@ -743,7 +743,7 @@ extern "C" int asr_sgemm(const asr_gemm_desc *din, void *stream) {
     // fast path: 16-byte aligned operands whose contiguous extent is a multiple of 4
     // (mode 1: a float4 that starts below M may run past it when the caller vouches that the row is
     // readable up to the next multiple of 4 -- those accumulator rows are never stored)
-    const bool fastA = vecA && (d.a_mode == 0 ? d.K % 4 == 0 : (d.M % 4 == 0 || (d.pad_ok & 1)));
+    const bool fastA = vecA && (d.a_mode == 0 ? (d.K % 4 == 0 || (d.pad_ok & 4)) : (d.M % 4 == 0 || (d.pad_ok & 1)));
     const bool fastB = vecB && (d.b_mode == 0 ? d.K % 4 == 0 : (d.N % 4 == 0 || (d.pad_ok & 2)));
     const bool fast = fastA && fastB;
     const int GK = (big && fast) ? gk_big : 16;

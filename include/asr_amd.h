@@ -150,7 +150,11 @@ typedef struct {
     int64_t batch_a1, batch_b1, batch_c1;
     /* bit 0 (A) / bit 1 (B), mode 1 operands only: every row is readable up to the next multiple of
      * 4 elements past M (resp. N) -- e.g. attention maps stored with a padded row stride -- so the
-     * 16-byte loads may be used although M (N) is not a multiple of 4 */
+     * 16-byte loads may be used although M (N) is not a multiple of 4.
+     * bit 2, A in mode 0 (k contiguous): every row of A is readable AND ZERO from K up to the next multiple of 4 -- the
+     * attention maps again, as the left operand of attn v / d ac k / d bd p (Models/Transformer_encoder.py:136), whose
+     * padding columns the softmax kernels keep at zero -- so K need not be a multiple of 4 for the 16-byte path (the
+     * rows of a mode-1 B operand are taken one k at a time and stop at K exactly) */
     int pad_ok;
     /* optional: bytes readable from A (resp. B), counted from the pointer in this descriptor (0 = unknown).  When both
      * are given and below 2 GiB the bf16 kernels fetch the operands with range-checked buffer loads (no per-load
