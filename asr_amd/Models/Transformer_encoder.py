@@ -456,12 +456,23 @@ class _CnnEmbeddingFunction(torch.autograd.Function):
             dwout = ops.transpose(dwoutp.view(-1, F2, Cc)).view(-1, Cc * F2)
             dw2 = ops.transpose(dw2p.view(Cc, 9, Cc)).view(Cc, Cc, 3, 3)
         dcol2 = _linear_dx(dpre2, w2p)
-        dpre1 = torch.empty_like(y1)                                        # col2im and the ReLU gradient in one pass
-        check(lib.asr_col2im_3x3s2(dcol2.data_ptr(), y1.data_ptr(), dpre1.data_ptr(), B, T1, F1, Cc, _st()))
-        dw1p = _e(Cc, 12, like=y1)
-        ops.matmul_tn(dpre1.view(-1, Cc), col1, dw1p)
-        db1 = _e(Cc, like=y1)
-        ops.colsum(dpre1.view(-1, Cc), db1)
+        if Cc % 4 == 0 and 256 % (Cc // 4) == 0:
+            # col2im, the ReLU gradient and the first convolution's weight / bias gradients in ONE pass: d pre1 (957 MB at
+            # config 5) is never written -- its only readers were dW1 = d pre1^T col1 and the bias column sum
+            part = _e(int(lib.asr_col2im_dw_blocks(B, T1, F1, Cc)), Cc * 10, like=y1)
+            check(lib.asr_col2im_3x3s2_dw(dcol2.data_ptr(), y1.data_ptr(), col1.data_ptr(), 12, part.data_ptr(), B, T1, F1,
+                                          Cc, _st()))
+            wb = _e(Cc * 10, like=y1)
+            ops.colsum(part, wb)
+            wb = wb.view(Cc, 10)
+            dw1p, db1 = wb, wb[:, 9].contiguous()
+        else:
+            dpre1 = torch.empty_like(y1)                                    # col2im and the ReLU gradient in one pass
+            check(lib.asr_col2im_3x3s2(dcol2.data_ptr(), y1.data_ptr(), dpre1.data_ptr(), B, T1, F1, Cc, _st()))
+            dw1p = _e(Cc, 12, like=y1)
+            ops.matmul_tn(dpre1.view(-1, Cc), col1, dw1p)
+            db1 = _e(Cc, like=y1)
+            ops.colsum(dpre1.view(-1, Cc), db1)
         return None, dw1p[:, :9].reshape(Cc, 1, 3, 3), db1, dw2, db2, dwout
 
 

@@ -170,6 +170,8 @@ SYMBOLS = {
                                           C.c_float, c_f]),
     "asr_im2col_3x3s2": (C.c_int, [c_f, c_f, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_f]),
     "asr_col2im_3x3s2": (C.c_int, [c_f, c_f, c_f, C.c_int, C.c_int, C.c_int, C.c_int, c_f]),
+    "asr_col2im_dw_blocks": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int]),
+    "asr_col2im_3x3s2_dw": (C.c_int, [c_f, c_f, c_f, C.c_int, c_f, C.c_int, C.c_int, C.c_int, C.c_int, c_f]),
 }
 
 _lib = None

@@ -723,6 +723,78 @@ __global__ __launch_bounds__(256) void col2im_3x3s2_v4_kernel(const float4 *__re
         dx[e] = acc;
     }
 }
+// The same gather for a map that is the FIRST convolution's output (one input channel, no gradient w.r.t. the
+// features): d pre-activation = relu'(y) * col2im(dcol) is not written at all -- the only readers would be the
+// first convolution's weight gradient dW1[c][tap] = sum_pos d pre[pos][c] * taps[pos][tap] and its bias gradient,
+// each a pass over the 957 MB map at config 5.  A thread keeps the 9 + 1 sums of its 4 channels in registers over
+// its grid-stride positions (its channel group is fixed: the stride is a multiple of C4), the block adds the
+// threads that share a channel group and writes one row of partials [C][10] (9 taps, then the bias): a column sum
+// over the rows finishes the job (asr_colsum).  taps: (B*Ti*Fi, ldt) rows of the first convolution's patches.
+#define C2I_MAXB 2048
+__global__ __launch_bounds__(256) void col2im_dw_v4_kernel(const float4 *__restrict__ dcol, const float4 *__restrict__ y,
+                                                           const float *__restrict__ taps, int ldt,
+                                                           float *__restrict__ part, int Ti, int Fi, int C4, int To,
+                                                           int Fo, int64_t n4, bool vect) {
+    __shared__ float red[256][41];
+    float4 sum[10];
+#pragma unroll
+    for (int k = 0; k < 10; ++k) sum[k] = zero4();
+    FOR_EACH(e, n4) {
+        int64_t q = e / C4;
+        const int64_t pos = q;
+        const int c = (int)(e - q * C4);
+        const int fi = (int)(q % Fi); q /= Fi;
+        const int ti = (int)(q % Ti);
+        const int64_t b = q / Ti;
+        float4 acc = zero4();
+#pragma unroll
+        for (int ki = 0; ki < 3; ++ki) {
+            const int t2 = ti - ki;
+            if (t2 < 0 || (t2 & 1) || t2 / 2 >= To) continue;
+#pragma unroll
+            for (int kj = 0; kj < 3; ++kj) {
+                const int f2 = fi - kj;
+                if (f2 < 0 || (f2 & 1) || f2 / 2 >= Fo) continue;
+                const float4 v = dcol[(((b * To + t2 / 2) * Fo + f2 / 2) * 9 + ki * 3 + kj) * C4 + c];
+                acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+            }
+        }
+        const float4 m = y[e];
+        acc.x = m.x > 0.f ? acc.x : 0.f; acc.y = m.y > 0.f ? acc.y : 0.f;
+        acc.z = m.z > 0.f ? acc.z : 0.f; acc.w = m.w > 0.f ? acc.w : 0.f;
+        const float *tp = taps + pos * ldt;
+        float tv[12];
+        if (vect) {      // rows of 12 floats, 16-byte aligned (host-checked): three loads instead of nine
+            const float4 t0 = ld4(tp), t1 = ld4(tp + 4), t2 = ld4(tp + 8);
+            tv[0] = t0.x; tv[1] = t0.y; tv[2] = t0.z; tv[3] = t0.w; tv[4] = t1.x; tv[5] = t1.y; tv[6] = t1.z; tv[7] = t1.w;
+            tv[8] = t2.x; tv[9] = t2.y; tv[10] = t2.z; tv[11] = t2.w;
+        } else {
+#pragma unroll
+            for (int k = 0; k < 9; ++k) tv[k] = tp[k];
+        }
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+            const float t = tv[k];
+            sum[k].x += acc.x * t; sum[k].y += acc.y * t; sum[k].z += acc.z * t; sum[k].w += acc.w * t;
+        }
+        sum[9].x += acc.x; sum[9].y += acc.y; sum[9].z += acc.z; sum[9].w += acc.w;
+    }
+    // threads tid, tid + C4, ... share a channel group (256 % C4 == 0, host-checked)
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int k = 0; k < 10; ++k) {
+        red[tid][4 * k] = sum[k].x; red[tid][4 * k + 1] = sum[k].y; red[tid][4 * k + 2] = sum[k].z; red[tid][4 * k + 3] = sum[k].w;
+    }
+    __syncthreads();
+    const int C = 4 * C4;
+    for (int i = tid; i < C * 10; i += 256) {
+        const int ch = i / 10, k = i - ch * 10;          // output element [ch][k]
+        const int g = ch >> 2, l = ch & 3;
+        float v = 0.f;
+        for (int t = g; t < 256; t += C4) v += red[t][4 * k + l];
+        part[(int64_t)blockIdx.x * C * 10 + i] = v;
+    }
+}
 // the data gradient as a gather: dx[b,ti,fi,c] = sum over the (ki, kj) whose output position exists
 __global__ __launch_bounds__(256) void col2im_3x3s2_kernel(const float *__restrict__ dcol, const float *__restrict__ y,
                                                            float *__restrict__ dx, int Ti, int Fi, int Cin, int To, int Fo,
@@ -762,6 +834,23 @@ extern "C" int asr_im2col_3x3s2(const float *x, float *col, int B, int Ti, int F
     hipLaunchKernelGGL(im2col_3x3s2_kernel, dim3(GRID1D(n)), dim3(256), 0, (hipStream_t)stream, x, col, Ti, Fi, Cin, To,
                        Fo, ld, n);
     ASR_CHECK_LAUNCH("im2col_3x3s2_kernel");
+    return ASR_OK;
+}
+extern "C" int asr_col2im_dw_blocks(int B, int Ti, int Fi, int Cin) {
+    const int64_t n4 = (int64_t)B * Ti * Fi * Cin / 4;
+    return (int)std::min<int64_t>((n4 + 255) / 256, C2I_MAXB);
+}
+extern "C" int asr_col2im_3x3s2_dw(const float *dcol, const float *y, const float *taps, int ldt, float *part, int B,
+                                   int Ti, int Fi, int Cin, void *stream) {
+    ASR_CHECK_ARG(dcol && y && taps && part && B > 0 && Ti >= 3 && Fi >= 3 && ldt >= 9, "col2im_3x3s2_dw: bad argument");
+    ASR_CHECK_ARG(Cin % 4 == 0 && Cin <= 1024 && 256 % (Cin / 4) == 0 && (((uintptr_t)dcol | (uintptr_t)y) & 15) == 0,
+                  "col2im_3x3s2_dw: Cin must be a multiple of 4 whose quarter divides 256, 16-byte aligned maps");
+    const int To = (Ti - 3) / 2 + 1, Fo = (Fi - 3) / 2 + 1;
+    const int64_t n4 = (int64_t)B * Ti * Fi * Cin / 4;
+    hipLaunchKernelGGL(col2im_dw_v4_kernel, dim3(asr_col2im_dw_blocks(B, Ti, Fi, Cin)), dim3(256), 0, (hipStream_t)stream,
+                       (const float4 *)dcol, (const float4 *)y, taps, ldt, part, Ti, Fi, Cin / 4, To, Fo, n4,
+                       ldt >= 12 && ldt % 4 == 0 && (((uintptr_t)taps) & 15) == 0);
+    ASR_CHECK_LAUNCH("col2im_dw_v4_kernel");
     return ASR_OK;
 }
 extern "C" int asr_col2im_3x3s2(const float *dcol, const float *y, float *dx, int B, int Ti, int Fi, int Cin,

@@ -450,6 +450,15 @@ int asr_relattn_softmax_bwd(const float *attn, float *dattn, float *dbd, const u
 int asr_im2col_3x3s2(const float *x, float *col, int B, int Ti, int Fi, int Cin, int ld, void *stream);
 int asr_col2im_3x3s2(const float *dcol, const float *y, float *dx, int B, int Ti, int Fi, int Cin,
                      void *stream);
+/* asr_col2im_3x3s2 for the map y that the FIRST convolution produced (one input channel, the features get no
+ * gradient): instead of writing relu'(y) * col2im(dcol), the kernel reduces it straight into the first
+ * convolution's weight and bias gradients -- part[blk][c][0..8] = sum_pos d pre[pos][c] * taps[pos][k],
+ * part[blk][c][9] = sum_pos d pre[pos][c] over the positions block blk visited; taps = the first convolution's
+ * patches (B*Ti*Fi rows of ldt >= 9 floats, asr_im2col_3x3s2's output).  asr_col2im_dw_blocks rows of Cin*10
+ * floats; asr_colsum over the rows gives [dW1 | db1].  Cin % 4 == 0 and (Cin / 4) must divide 256. */
+int asr_col2im_dw_blocks(int B, int Ti, int Fi, int Cin);
+int asr_col2im_3x3s2_dw(const float *dcol, const float *y, const float *taps, int ldt, float *part, int B, int Ti,
+                        int Fi, int Cin, void *stream);
 
 /* ------------------------------------------------- attention decoder loop --
  * Replaces the L-step teacher-forced loop Models/decoder.py:52-60 with
