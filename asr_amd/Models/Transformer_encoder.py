@@ -50,16 +50,9 @@ def _exact(fn):
     return wrapped
 
 
-# The forward products of the Conv2d subsampling keep a setting of their own (see the top of the file).
+# The forward products of the two Conv2d of the subsampling -- the ones in front of a ReLU -- keep a setting of their
+# own (see the top of the file); its output Linear takes the general mode.
 CNN_FWD_GEMM_PRECISION = os.environ.get("ASR_CONFORMER_CNN_FWD_GEMM_PRECISION", "f32")
-
-
-def _exact_cnn_fwd(fn):
-    @functools.wraps(fn)
-    def wrapped(*a, **k):
-        with ops.gemm_precision(CNN_FWD_GEMM_PRECISION):
-            return fn(*a, **k)
-    return wrapped
 
 
 def _st():
@@ -414,7 +407,7 @@ class _CnnEmbeddingFunction(torch.autograd.Function):
     weight is used as its (odim, F2, C) permutation.  No gradient w.r.t. the features (they are data)."""
 
     @staticmethod
-    @_exact_cnn_fwd
+    @_exact
     def forward(ctx, src, w1, b1, w2, b2, wout):
         lib = _lib.load()
         B, T, F = src.shape
@@ -427,12 +420,16 @@ class _CnnEmbeddingFunction(torch.autograd.Function):
         check(lib.asr_im2col_3x3s2(src.data_ptr(), col1.data_ptr(), B, T, F, 1, 12, _st()))
         w1p = torch.zeros(Cc, 12, device=src.device, dtype=torch.float32)
         w1p[:, :9].copy_(w1.view(Cc, 9))
-        y1 = _linear(col1, w1p, b1, act=2)                                  # (B,T1,F1,C)
+        with ops.gemm_precision(CNN_FWD_GEMM_PRECISION):                    # the two products in front of a ReLU
+            y1 = _linear(col1, w1p, b1, act=2)                              # (B,T1,F1,C)
         col2 = _e(B * T2 * F2, 9 * Cc, like=src)
         check(lib.asr_im2col_3x3s2(y1.data_ptr(), col2.data_ptr(), B, T1, F1, Cc, 9 * Cc, _st()))
         w2p = ops.transpose(w2.view(Cc, Cc, 9)).view(Cc, 9 * Cc)            # (Cout, ki, kj, Cin)
-        y2 = _linear(col2, w2p, b2, act=2)                                  # (B,T2,F2,C)
+        with ops.gemm_precision(CNN_FWD_GEMM_PRECISION):
+            y2 = _linear(col2, w2p, b2, act=2)                              # (B,T2,F2,C)
         woutp = ops.transpose(wout.view(-1, Cc, F2)).view(-1, F2 * Cc)      # (odim, F2, C)
+        # the output Linear has no ReLU behind it (no mask for round-off to flip, see CNN_FWD_GEMM_PRECISION): it takes
+        # the encoder's general arithmetic like every other Linear of the model
         out = _linear(y2.view(B * T2, F2 * Cc), woutp)
         ctx.save_for_backward(col1, y1, col2, y2, w2p, woutp)
         ctx.dims = (B, T1, F1, T2, F2, Cc)
