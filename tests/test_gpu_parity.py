@@ -16,6 +16,11 @@ pytestmark = pytest.mark.gpu
 LOSS_TOL, OUT_TOL, GRAD_TOL = 1e-4, 1e-4, 1e-3
 
 
+def _lib_prec():
+    from asr_amd import _lib
+    return int(_lib.load().asr_gemm_precision(-1))
+
+
 def _dev():
     assert torch.cuda.is_available(), "GPU tests need a GPU: refusing to pass on a fallback"
     return torch.device("cuda:0")
@@ -127,6 +132,8 @@ def test_dropout_packed_output_and_presplit_weight_gradient():
     from asr_amd import _lib, ops
     import ctypes as C
     lib = _lib.load()
+    if lib.asr_gemm_precision(-1) != 1:
+        pytest.skip("the pre-split kernels belong to the bf16x3 mode (ASR_GEMM_PRECISION selects another one here)")
     dev = _dev()
     T, B, D, H8 = 400, 32, 640, 2560
     g = torch.Generator().manual_seed(5)
@@ -220,6 +227,8 @@ def test_sgemm_presplit_weights_bit_identical(M, N, K, b_mode):
     w_bits = W.view(torch.int32)
     assert bool(((w_words >> 16) - (w_bits >> 16)).abs().max() <= 1)          # the hi half is bf16(x): top 16 bits, rounded
     bs = K if b_mode == 0 else N
+    if _lib_prec() != 1:
+        pytest.skip("the pre-split kernels belong to the bf16x3 mode (ASR_GEMM_PRECISION selects another one here)")
     assert ops.packed_ok(rows.numel(), N)
     outs = []
     for pk in (None, (Wp, bs)):
@@ -556,6 +565,8 @@ def test_golden_forward_backward_with_side_stream(name):
     lengths = torch.from_numpy(z["lengths"])
     targets = torch.from_numpy(z["targets"]).to(dev)
     tl = torch.from_numpy(z["text_lengths"]).to(dev)
+    if streams._FORCED_OFF:
+        pytest.skip("ASR_SIDE_STREAM=0 forces the side stream off in this environment")
     streams.enable(True)
     try:
         assert streams.ENABLED
@@ -1107,6 +1118,8 @@ def test_blstm_data_parallel_rehearsal_group_of_one_then_side_stream():
     from asr_amd.Models.AttModel import AttModel
     from asr_amd.parallel import BucketedGradReducer
     from oracle import ref_model as R
+    if streams._FORCED_OFF:
+        pytest.skip("ASR_SIDE_STREAM=0 forces the side stream off in this environment")
     dev = _dev()
     hp = R.make_hp(lmfb_dim=12, frame_stacking=1, num_hidden_nodes=32, num_encoder_layer=3, num_classes=21,
                    encoder_dropout=0.0)
