@@ -2176,7 +2176,7 @@ __global__ __launch_bounds__(256) void phase2_tile_kernel(
 #pragma unroll
             for (int c = 0; c < NCH; ++c) x += Fv[r * NCH + c] * wfe2[c];
             const f32x2 th = {tanh_f(x.x), tanh_f(x.y)};
-            const f32x2 dp = dev[r] * (1.f - th * th) * wee2;
+            const f32x2 dp = dev[r] * (1.f - th * th);       // w_ee[a], a factor of every term of both sums, is applied once at the end
             acc_ph2[r] += dp;
             acc_ee2 += dev[r] * th;
 #pragma unroll
@@ -2202,7 +2202,7 @@ __global__ __launch_bounds__(256) void phase2_tile_kernel(
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int t = tf + 4 * q + r;
-            if (av[n] && t < T) dPH[((int64_t)b * T + t) * A + a] = acc_ph2[r][n];
+            if (av[n] && t < T) dPH[((int64_t)b * T + t) * A + a] = acc_ph2[r][n] * wee2[n];
         }
         float e = acc_ee2[n];
         e += __shfl_xor(e, 16, 64);
@@ -2213,7 +2213,7 @@ __global__ __launch_bounds__(256) void phase2_tile_kernel(
             float v = afe[c][n];
             v += __shfl_xor(v, 16, 64);
             v += __shfl_xor(v, 32, 64);
-            if (q == 0) fe_s[wave][n][c][col] = v;
+            if (q == 0) fe_s[wave][n][c][col] = v * wee2[n];
         }
     }
     __syncthreads();
