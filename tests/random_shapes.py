@@ -1,5 +1,5 @@
-"""Random shapes through the encoder / decoder / Conformer-encoder parity checks of tests/test_gpu_parity.py and
-tests/test_gpu_conformer.py (the HIP path
+"""Random shapes through the encoder / decoder / Conformer-encoder / CTC / label-smoothing parity checks of
+tests/test_gpu_parity.py, tests/test_gpu_conformer.py and tests/test_gpu_ctc.py (the HIP path
 against the CPU oracle in float64): the comparisons of test_blstm_vs_oracle and test_decoder_vs_oracle with shapes drawn at
 random instead of the fixed lists -- widths that are and are not multiples of 4 / 16, batches above and below the
 persistent kernels' limit of 32, lengths down to 1, one label step.  Sizes stay small enough for the oracle.
@@ -122,6 +122,51 @@ def conformer_case(B, T, idim, d, N_e, heads, lens):
     return eo, errs, eo32
 
 
+def ctc_case(B, T, V, L, hi, seed):
+    """The comparison of tests/test_gpu_ctc.py::test_ctc_kernel_vs_oracle (train.py:56-57 in float64)."""
+    from oracle import ref_ctc as RC
+    from asr_amd.Loss.ctc import ctc_loss
+    g = torch.Generator().manual_seed(seed)
+    z = torch.randn(B, T, V, generator=g) * 2
+    tgt = torch.randint(1, max(hi, 2), (B, L), generator=g) if L > 0 else torch.zeros(B, 0, dtype=torch.int64)
+    tl = torch.randint(0, L + 1, (B,), generator=g)
+    tl[0] = L
+    # every utterance long enough for its labels (repeats need a blank between them)
+    need = torch.tensor([int(tl[b]) + int((tgt[b, 1:tl[b]] == tgt[b, :max(int(tl[b]) - 1, 0)]).sum()) for b in range(B)])
+    il = torch.maximum(torch.randint(1, T + 1, (B,), generator=g), need).clamp(max=T)
+    il[0] = T
+    if not bool((il >= need).all()):
+        return None                              # infeasible draw (T too short for the repeats): skipped
+    for b in range(B):
+        tgt[b, tl[b]:] = 0
+    zz = z.double().requires_grad_(True)
+    want = RC.ctc_loss_train(zz, tgt, il, tl)
+    want_g, = torch.autograd.grad(want, zz)
+    zd = z.to(dev).requires_grad_(True)
+    loss = ctc_loss(zd, tgt.to(dev), il, tl.to(dev), blank=0)
+    loss.backward()
+    for b in range(B):                           # frames past the input length: exactly zero gradient
+        assert il[b] == T or float(zd.grad[b, int(il[b]):].abs().max()) == 0.0
+    el = abs(float(loss.detach()) - float(want.detach())) / max(abs(float(want.detach())), 1e-30)
+    return el, {"logits": (rel_err(zd.grad.cpu(), want_g), float(want_g.abs().max()))}
+
+
+def loss_case(B, L, V, T_norm, B_norm, seed):
+    """The comparison of tests/test_gpu_parity.py::test_loss_kernel_vs_oracle (label_smoothing.py:14-28)."""
+    from asr_amd.Loss.label_smoothing import label_smoothing_loss
+    g = torch.Generator().manual_seed(seed)
+    z = (torch.randn(B, L, V, generator=g) * 3).requires_grad_(True)
+    tgt = torch.randint(0, V, (B, L), generator=g)
+    tl = torch.randint(1, L + 1, (B,), generator=g)
+    want = R.label_smoothing_loss(z.double(), tgt, tl, T_norm, B_norm)
+    gw, = torch.autograd.grad(want, z)
+    zd = z.detach().to(dev).requires_grad_(True)
+    got = label_smoothing_loss(zd, tgt.to(dev), tl.to(dev), T_norm, B_norm)
+    got.backward()
+    el = abs(float(got.detach()) - float(want.detach())) / max(abs(float(want.detach())), 1e-30)
+    return el, {"logits": (rel_err(zd.grad.cpu(), gw), float(gw.abs().max()))}
+
+
 def run(n, seed, quiet=False):
     """n random cases from ``seed``; returns the number of cases outside the bars."""
     say = (lambda *a, **k: None) if quiet else print
@@ -129,7 +174,7 @@ def run(n, seed, quiet=False):
     lib = _lib.load()
     t0, worst_o, worst_g, bad = time.time(), 0.0, 0.0, 0
     for i in range(n):
-        kind = rng.choice(["blstm", "blstm", "decoder", "decoder", "conformer"])
+        kind = rng.choice(["blstm", "blstm", "decoder", "decoder", "conformer", "ctc", "loss"])
         if kind == "blstm":
             B = rng.choice([1, 2, 3, 7, 16, 17, 31, 32, 33, 40])
             T = rng.choice([1, 2, 3, 5, 16, 17, 31, 64, 65, 90])
@@ -146,6 +191,25 @@ def run(n, seed, quiet=False):
                 eo, errs = blstm_case(*args)
             finally:
                 lib.asr_blstm_precision(old)
+        elif kind == "ctc":
+            B, T = rng.choice([1, 2, 3, 8, 33]), rng.choice([1, 2, 9, 30, 64, 130])
+            V = rng.choice([2, 3, 5, 37, 100, 1000, 1001])
+            L = rng.choice([0, 1, 2, 5, 20, 60])
+            L = min(L, T)
+            args = (B, T, V, L, min(V, rng.choice([2, 3, V])), rng.randrange(1 << 30))     # labels in [1, hi): few distinct = many repeats
+            say(i, kind, args, end=" ", flush=True)
+            r = ctc_case(*args)
+            if r is None:
+                say("skipped (infeasible draw)", flush=True)
+                continue
+            eo, errs = r
+        elif kind == "loss":
+            args = (rng.choice([1, 2, 7, 32, 40]), rng.choice([1, 2, 5, 30, 100]), rng.choice([2, 3, 11, 37, 1000, 1001, 7000]),
+                    rng.choice([True, False]), rng.choice([True, False]), rng.randrange(1 << 30))
+            if args[0] * args[1] * args[2] > 5000000:          # the oracle builds dense one-hot rows in float64
+                args = (max(1, 5000000 // (args[1] * args[2])),) + args[1:]
+            say(i, kind, args, end=" ", flush=True)
+            eo, errs = loss_case(*args)
         elif kind == "conformer":
             B = rng.choice([1, 2, 3, 5])
             T = rng.choice([7, 8, 11, 12, 15, 16, 30, 45, 64, 90])
