@@ -53,20 +53,17 @@ class AttModel(nn.Module):
         return self.decoder(hbatch, lengths_dev, targets)
 
     def decode(self, x, lengths, model_lm=None, src_pos=None):
-        if model_lm is not None:
-            raise NotImplementedError("asr_amd.AttModel.decode: LM shallow fusion is outside the path")
+        """Models/AttModel.py:31-39; ``model_lm``: shallow fusion with ``hp.lm_weight`` (Decoder.decode)."""
         with torch.no_grad():
             hbatch = self._encode(x, lengths, src_pos)
             if hbatch is None:
                 hbatch = self.encoder(x, lengths)
-            return self.decoder.decode(hbatch, lengths, None)
+            return self.decoder.decode(hbatch, lengths, model_lm)
 
     def decode_v2(self, x, lengths, model_lm=None, src_pos=None):
         """Models/AttModel.py:41-49."""
-        if model_lm is not None:
-            raise NotImplementedError("asr_amd.AttModel.decode_v2: LM shallow fusion is outside the path")
         with torch.no_grad():
             hbatch = self._encode(x, lengths, src_pos)
             if hbatch is None:
                 hbatch = self.encoder(x, lengths)
-            return self.decoder.decode_v2(hbatch, lengths, None)
+            return self.decoder.decode_v2(hbatch, lengths, model_lm)

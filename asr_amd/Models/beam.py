@@ -1,5 +1,8 @@
-"""Beam search on the device kernels (batch 1, no LM fusion): ``beam_decode`` = Models/decoder.py:63-130
-with beam_width > 1, ``beam_decode_v2`` = the second search, Models/decoder.py:132-267 (decode_v2).
+"""Beam search on the device kernels (batch 1): ``beam_decode`` = Models/decoder.py:63-130
+with beam_width > 1 (or any width with a language model), ``beam_decode_v2`` = the second search,
+Models/decoder.py:132-267 (decode_v2).  Shallow fusion (:93-96, :180-183): ``model_lm`` is any callable
+``tokens (n, len) int64 on the device -> scores (n, len, V)``; the live hypotheses go through it as ONE batch per
+step (they all have the same length) where the reference's decode() calls it once per hypothesis.
 
 The live hypotheses are the batch dimension of the same per-step kernels the training forward
 uses (asr_attdec_step_att / asr_attdec_step_cell); scoring, the per-hypothesis top-k and the
@@ -90,7 +93,19 @@ class _Stepper:
         return S2[1], C2[1]
 
 
-def beam_decode(dec, hbatch, lengths, beam_width, max_len, eos_id, score_func="log_softmax"):
+def _fuse_lm(y, seqs, model_lm, lm_weight, score_func, dev):
+    """y + lm_weight * log_softmax(model_lm(seqs)[:, -1]) (Models/decoder.py:94-96, :181-183); the reference's
+    'softmax' branch with an LM (:101-106, :188-193) reads scores it never assigned, so that combination is refused."""
+    if score_func != "log_softmax":
+        raise ValueError("shallow fusion needs score_func == 'log_softmax' (the reference's softmax branch is broken)")
+    lm_score = model_lm(torch.tensor(seqs, dtype=torch.int64, device=dev))[:, -1, :]
+    if lm_score.shape != y.shape:
+        raise RuntimeError(f"model_lm returned scores of shape {tuple(lm_score.shape)}, expected {tuple(y.shape)}")
+    return y + float(lm_weight) * F.log_softmax(lm_score.to(y.dtype), dim=1)
+
+
+def beam_decode(dec, hbatch, lengths, beam_width, max_len, eos_id, score_func="log_softmax", model_lm=None,
+                lm_weight=0.0):
     """Returns (result, trace): ``result`` is what the reference's decode() returns (the best
     hypothesis as soon as it ends in eos, else [] after ``max_len`` steps); trace[k] = the
     survivors of step k as (tokens, score)."""
@@ -112,6 +127,8 @@ def beam_decode(dec, hbatch, lengths, beam_width, max_len, eos_id, score_func="l
         n = len(seqs)
         g, alpha, Y = k.att(S, Cc, alpha_prev)
         y = F.log_softmax(Y, dim=1) if score_func == "log_softmax" else F.softmax(Y, dim=1)
+        if model_lm is not None and (score_func != "log_softmax" or len(seqs[0]) > 0):     # :93: not on the first step
+            y = _fuse_lm(y, seqs, model_lm, lm_weight, score_func, k.dev)
         kk = min(W, k.V)
         vals, idx = torch.topk(y, kk, dim=1)                    # the repeated argmax of :109-116
         cand = (scores.view(n, 1) + vals).reshape(-1)           # hypothesis-major, like the append order
@@ -132,7 +149,8 @@ def beam_decode(dec, hbatch, lengths, beam_width, max_len, eos_id, score_func="l
     return [], trace
 
 
-def beam_decode_v2(dec, hbatch, lengths, beam_width, max_len, eos_id, score_func="log_softmax"):
+def beam_decode_v2(dec, hbatch, lengths, beam_width, max_len, eos_id, score_func="log_softmax", model_lm=None,
+                   lm_weight=0.0):
     """Models/decoder.py:132-267 (decode_v2) on the device kernels.
 
     The ``beam_width`` live hypotheses are the batch rows of one attention step; each proposes its
@@ -169,6 +187,8 @@ def beam_decode_v2(dec, hbatch, lengths, beam_width, max_len, eos_id, score_func
     for step in range(int(max_len)):
         g, alpha, Y = k.att(S, Cc, alpha_prev)
         y = F.log_softmax(Y, dim=1) if score_func == "log_softmax" else F.softmax(Y, dim=1)
+        if model_lm is not None and (score_func != "log_softmax" or step > 0):              # :180: from the second step on
+            y = _fuse_lm(y, seqs, model_lm, lm_weight, score_func, dev)
         best, idx = torch.topk(y, W, dim=1)
         cand = score.view(W, 1) + best + 1
         if step == 0:

@@ -275,34 +275,33 @@ class Decoder(nn.Module):
 
     @torch.no_grad()
     def decode(self, hbatch, lengths, model_lm=None):
-        """Models/decoder.py:63-130 (batch 1, no LM): greedy for ``hp.beam_width == 1``, beam
-        search otherwise.
+        """Models/decoder.py:63-130 (batch 1): greedy for ``hp.beam_width == 1``, beam search otherwise.
 
         Runs the same per-step kernels as training.  Returns the best hypothesis once it ends in
         ``hp.eos_id`` within ``hp.max_decoder_seq_len`` steps, else ``[]`` -- exactly what the
-        reference returns.
+        reference returns.  ``model_lm`` (shallow fusion, :93-96): a callable ``tokens (n, len) int64 on the device
+        -> scores (n, len, V)``, weighted by ``hp.lm_weight``; log_softmax scoring only (beam.py::_fuse_lm).
         """
-        if model_lm is not None:
-            raise NotImplementedError("asr_amd.Decoder.decode: LM shallow fusion is outside the path")
         width = int(getattr(self.hp, "beam_width", 1))
-        if width > 1:
+        if width > 1 or model_lm is not None:
             from .beam import beam_decode
             return beam_decode(self, hbatch, lengths, width, self.hp.max_decoder_seq_len, self.hp.eos_id,
-                               getattr(self.hp, "score_func", "log_softmax"))[0]
+                               getattr(self.hp, "score_func", "log_softmax"), model_lm,
+                               self.hp.lm_weight if model_lm is not None else 0.0)[0]
         return self.decode_raw(hbatch, lengths)[0]
 
     @torch.no_grad()
     def decode_v2(self, hbatch, lengths, model_lm=None):
-        """Models/decoder.py:132-267 (batch 1, no LM): the second beam search -- finished
+        """Models/decoder.py:132-267 (batch 1): the second beam search -- finished
         hypotheses are collected in ``hp.beam_width`` result slots and the best-scoring slot is
-        returned (see ``beam.beam_decode_v2`` for the rules, including when [] comes back).  The
+        returned (see ``beam.beam_decode_v2`` for the rules, including when [] comes back).  ``model_lm``: shallow
+        fusion (:180-183), as in ``decode``.  The
         reference's trailing matplotlib / sentencepiece imports (:261-264) have no effect on the
         result and are not mirrored."""
-        if model_lm is not None:
-            raise NotImplementedError("asr_amd.Decoder.decode_v2: LM shallow fusion is outside the path")
         from .beam import beam_decode_v2
         return beam_decode_v2(self, hbatch, lengths, int(self.hp.beam_width), self.hp.max_decoder_seq_len,
-                              self.hp.eos_id, getattr(self.hp, "score_func", "log_softmax"))[0]
+                              self.hp.eos_id, getattr(self.hp, "score_func", "log_softmax"), model_lm,
+                              self.hp.lm_weight if model_lm is not None else 0.0)[0]
 
     @torch.no_grad()
     def decode_raw(self, hbatch, lengths):

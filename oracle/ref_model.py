@@ -14,6 +14,8 @@ Reference lines followed (paths relative to /root/reference):
 * location attention .... Models/attention.py:24-40
 * decoder loop + cell ... Models/decoder.py:36-61, 269-279
 * greedy decode ......... Models/decoder.py:63-130  (beam_width == 1)
+* beam searches ......... Models/decoder.py:63-130 (beam_width > 1), :132-267 (decode_v2), with the shallow-fusion
+                          lines :93-96 / :180-183 (pinned by tests/golden/v2 and tests/golden/lm)
 * label smoothing ....... Loss/label_smoothing.py:14-28
 
 Parity pin: ``tests/golden/*.npz`` were produced by importing the reference
@@ -202,8 +204,12 @@ class Decoder(nn.Module):
 
 
     @torch.no_grad()
-    def decode_beam(self, hbatch, lengths, beam_width, max_len, eos_id, score_func="log_softmax"):
-        """Models/decoder.py:63-130 with beam_width >= 1 (batch 1, no LM).
+    def decode_beam(self, hbatch, lengths, beam_width, max_len, eos_id, score_func="log_softmax", model_lm=None,
+                    lm_weight=0.0):
+        """Models/decoder.py:63-130 with beam_width >= 1 (batch 1).  Shallow fusion (:93-96): a hypothesis that already
+        holds tokens adds ``lm_weight * log_softmax(model_lm(its tokens)[:, -1])`` to its log-probabilities before its
+        best tokens are picked; the first step has no LM term.  With score_func == 'softmax' the reference's LM branch
+        (:101-104) never assigns the scores it then reads: not restated (ValueError).
 
         Every live hypothesis is advanced by one attention step, its ``beam_width`` best tokens
         (repeated argmax, :109-116) become candidates scored ``old score + (log-)probability``
@@ -224,6 +230,12 @@ class Decoder(nn.Module):
                 y = self.L_yy(torch.tanh(self.L_gy(g) + self.L_sy(s)))
                 y = F.log_softmax(y, dim=1) if score_func == "log_softmax" else F.softmax(y, dim=1)
                 tmpy = y.clone()
+                if model_lm is not None:
+                    if score_func != "log_softmax":
+                        raise ValueError("shallow fusion is defined for score_func == 'log_softmax' only (decoder.py:101-106)")
+                    if len(seq) > 0:
+                        lm_score = model_lm(torch.tensor([seq], dtype=torch.int64))[:, -1, :]
+                        tmpy = y + lm_weight * F.log_softmax(lm_score.to(y.dtype), dim=1)
                 for _k in range(beam_width):
                     best = tmpy.argmax(1)
                     cand_score = score + float(tmpy[0, best])
@@ -239,8 +251,12 @@ class Decoder(nn.Module):
         return [], trace
 
     @torch.no_grad()
-    def decode_beam_v2(self, hbatch, lengths, beam_width, max_len, eos_id, score_func="log_softmax"):
-        """Models/decoder.py:132-267 (decode_v2, batch 1, no LM): the second beam search.
+    def decode_beam_v2(self, hbatch, lengths, beam_width, max_len, eos_id, score_func="log_softmax", model_lm=None,
+                       lm_weight=0.0):
+        """Models/decoder.py:132-267 (decode_v2, batch 1): the second beam search.  Shallow fusion (:180-183): from the
+        second step on, ``lm_weight * log_softmax(model_lm(live sequences (W, step))[:, -1])`` is added to the rows'
+        log-probabilities before the top-k; 'softmax' scoring with an LM is broken in the reference (:188-193) and
+        not restated (ValueError).
 
         The ``beam_width`` live hypotheses are the batch rows of one attention step (:172-176; all
         rows start from the zero state, :146-151).  Each row proposes its ``beam_width`` best tokens
@@ -274,6 +290,12 @@ class Decoder(nn.Module):
             g, alpha_n = self.att(s, hbatch, alpha, e_mask)
             y = self.L_yy(torch.tanh(self.L_gy(g) + self.L_sy(s)))
             y = F.log_softmax(y, dim=1) if score_func == "log_softmax" else F.softmax(y, dim=1)
+            if model_lm is not None:
+                if score_func != "log_softmax":
+                    raise ValueError("shallow fusion is defined for score_func == 'log_softmax' only (decoder.py:188-193)")
+                if step > 0:
+                    lm_score = model_lm(torch.tensor(seqs, dtype=torch.int64))[:, -1, :]
+                    y = y + lm_weight * F.log_softmax(lm_score.to(y.dtype), dim=1)
             best, idx = y.topk(W, dim=1)
             cand = score.unsqueeze(1) + best + 1
             if step == 0:
@@ -327,9 +349,10 @@ class AttModel(nn.Module):
     def decode(self, x, lengths, model_lm=None, src_pos=None):
         with torch.no_grad():
             hbatch = self.encoder(x, lengths)
-            if getattr(self.hp, "beam_width", 1) > 1:
+            if getattr(self.hp, "beam_width", 1) > 1 or model_lm is not None:
                 return self.decoder.decode_beam(hbatch, lengths, self.hp.beam_width, self.hp.max_decoder_seq_len,
-                                                self.hp.eos_id, getattr(self.hp, "score_func", "log_softmax"))[0]
+                                                self.hp.eos_id, getattr(self.hp, "score_func", "log_softmax"),
+                                                model_lm, getattr(self.hp, "lm_weight", 0.0))[0]
             return self.decoder.decode_greedy(
                 hbatch, lengths, self.hp.max_decoder_seq_len, self.hp.eos_id)[0]
 
@@ -338,7 +361,8 @@ class AttModel(nn.Module):
         with torch.no_grad():
             hbatch = self.encoder(x, lengths)
             return self.decoder.decode_beam_v2(hbatch, lengths, self.hp.beam_width, self.hp.max_decoder_seq_len,
-                                               self.hp.eos_id, getattr(self.hp, "score_func", "log_softmax"))[0]
+                                               self.hp.eos_id, getattr(self.hp, "score_func", "log_softmax"),
+                                               model_lm, getattr(self.hp, "lm_weight", 0.0))[0]
 
 
 # --------------------------------------------------------------------------

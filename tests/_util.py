@@ -58,3 +58,33 @@ def greedy_raw_from_table(table):
         if len(r) > len(best):
             best = r
     return best
+
+
+class TinyLM(torch.nn.Module):
+    """A deterministic stand-in for the language model of shallow fusion (Models/decoder.py:93-96,180-183 call
+    ``model_lm(tokens (n, len) int64)[:, -1, :]``): score[b, t] = W tanh(mean of the embeddings of tokens 0..t) + bias,
+    causal and row-independent like a real LM.  Used by oracle/make_golden_lm.py (with the reference) and by the tests
+    (with the oracle and the HIP path) with the weights stored in tests/golden/lm/*.npz."""
+
+    def __init__(self, V, width=8):
+        super().__init__()
+        self.emb = torch.nn.Embedding(V, width)
+        self.out = torch.nn.Linear(width, V)
+
+    def forward(self, tokens):
+        e = self.emb(tokens)                                            # (n, len, width)
+        steps = torch.arange(1, tokens.shape[1] + 1, device=e.device, dtype=e.dtype).view(1, -1, 1)
+        return self.out(torch.tanh(torch.cumsum(e, 1) / steps))
+
+
+LM_CASES = ("tiny_a", "tiny_b", "long_t")
+LM_RUNS = (("lmgreedy", "decode", 1), ("lmbeam3", "decode", 3), ("lmv2beam3", "decode_v2", 3))
+
+
+def load_lm(name):
+    """tests/golden/lm/<name>.npz -> (npz, TinyLM with its stored weights, lm_weight)."""
+    import os
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "lm", name + ".npz"), allow_pickle=False)
+    lm = TinyLM(z["lm.emb.weight"].shape[0], z["lm.emb.weight"].shape[1])
+    lm.load_state_dict({k[len("lm."):]: torch.from_numpy(z[k]) for k in z.files if k.startswith("lm.")})
+    return z, lm.eval(), float(z["lm_weight"])

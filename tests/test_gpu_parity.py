@@ -5,11 +5,14 @@ Tolerances are the north star's fp32 bar: loss rel-err <= 1e-4, gradients
 <= 1e-3 (scale-relative max error, tests/_util.rel_err); youtput <= 1e-4.
 Greedy decoding must be token-identical.
 """
+import copy
+
 import numpy as np
 import pytest
 import torch
 
-from tests._util import CASES, V2_CASES, V2_RUNS, load_case, load_v2, params_of, rel_err, greedy_raw_from_table
+from tests._util import (CASES, LM_CASES, LM_RUNS, V2_CASES, V2_RUNS, load_case, load_lm, load_v2, params_of, rel_err,
+                         greedy_raw_from_table)
 
 pytestmark = pytest.mark.gpu
 
@@ -895,7 +898,7 @@ def test_golden_beam_v2_tokens(name):
 
 def test_beam_v2_errors():
     """The reference raises RuntimeError for unequal encoder/decoder widths (decoder.py:219,241)
-    and for widths its topk calls reject; LM fusion is outside the path."""
+    and for widths its topk calls reject; an LM together with softmax scoring is refused."""
     from asr_amd.Models.beam import beam_decode_v2
     z, hp = load_case("mixed_h")
     dev = _dev()
@@ -915,8 +918,57 @@ def test_beam_v2_errors():
     for width in (1, hp.num_classes + 1):
         with pytest.raises(RuntimeError):
             beam_decode_v2(m.decoder, hb, lengths, width, 5, 1)
-    with pytest.raises(NotImplementedError):
-        m.decode_v2(x, lengths, model_lm=object())
+    hp.score_func, hp.lm_weight, hp.beam_width = "softmax", 0.5, 3      # an LM with softmax scoring is broken in the reference: refused
+    with pytest.raises(ValueError):
+        m.decode_v2(x, lengths, model_lm=lambda t: torch.zeros(t.shape[0], t.shape[1], hp.num_classes, device=t.device))
+
+
+@pytest.mark.parametrize("name", LM_CASES)
+def test_golden_shallow_fusion_tokens(name):
+    """decode / decode_v2 with a language model (Models/decoder.py:93-96, :180-183) on the device kernels:
+    token-identical to what the REFERENCE returned with the same LM (tests/golden/lm: widths 1 and 3 of decode, width
+    3 of decode_v2, lm_weight 0.7) for every eos id, through the module interface; and with an eos id that never
+    occurs the survivors of every step equal the oracle's (same sequences, same order, scores to 1e-4)."""
+    from asr_amd.Models.beam import beam_decode, beam_decode_v2
+    from oracle import ref_model as R
+    z, hp = load_case(name)
+    g, lm, lm_weight = load_lm(name)
+    dev = _dev()
+    m = _build(hp, params_of(z)).eval()
+    ref = R.AttModel(hp)
+    ref.load_state_dict(params_of(z))
+    ref.eval()
+    lm_dev = copy.deepcopy(lm).to(dev)
+    x = torch.from_numpy(z["x"])
+    lengths = torch.from_numpy(z["lengths"])
+    max_len = int(g["max_len"])
+    hp.max_decoder_seq_len, hp.lm_weight, hp.score_func = max_len, lm_weight, "log_softmax"
+    changed = 0
+    for tag, fn, width in LM_RUNS:
+        hp.beam_width = width
+        for utt in range(2):
+            xu, lu = x[utt:utt + 1], lengths[utt:utt + 1]
+            with torch.no_grad():
+                hb, hr = m.encoder(xu.to(dev), lu), ref.encoder(xu, lu)
+            if fn == "decode":
+                _, trace = beam_decode(m.decoder, hb, lu, width, max_len, -1, "log_softmax", lm_dev, lm_weight)
+                _, want_trace = ref.decoder.decode_beam(hr, lu, width, max_len, -1, "log_softmax", lm, lm_weight)
+            else:
+                _, trace = beam_decode_v2(m.decoder, hb, lu, width, max_len, -1, "log_softmax", lm_dev, lm_weight)
+                _, want_trace = ref.decoder.decode_beam_v2(hr, lu, width, max_len, -1, "log_softmax", lm, lm_weight)
+                trace, want_trace = [t[0] for t in trace], [t[0] for t in want_trace]
+            assert len(trace) == len(want_trace) == max_len
+            for got_step, want_step in zip(trace, want_trace):
+                assert [s_ for s_, _ in got_step] == [s_ for s_, _ in want_step]
+                for (_, a_), (_, b_) in zip(got_step, want_step):
+                    assert abs(a_ - b_) < 1e-4 * max(1.0, abs(b_))
+            table = g[f"{tag}.utt{utt}"]
+            for eos in range(hp.num_classes):
+                hp.eos_id = eos
+                got = getattr(m, fn)(xu.to(dev), lu, lm_dev)
+                assert got == [int(v) for v in table[eos] if v >= 0], (tag, utt, eos)
+                changed += got != getattr(m, fn)(xu.to(dev), lu)
+    assert changed > 0
 
 
 # ------------------------------------------------ optimizer step (SURVEY 8f rank 1) --

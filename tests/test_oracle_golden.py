@@ -4,7 +4,8 @@ import pytest
 import torch
 
 from oracle import ref_model as R
-from tests._util import CASES, V2_CASES, V2_RUNS, load_case, load_v2, params_of, rel_err, greedy_raw_from_table
+from tests._util import (CASES, LM_CASES, LM_RUNS, V2_CASES, V2_RUNS, load_case, load_lm, load_v2, params_of, rel_err,
+                         greedy_raw_from_table)
 
 
 @pytest.mark.parametrize("name", CASES)
@@ -138,6 +139,37 @@ def test_beam_v2_tokens(name):
                 assert got == want, (tag, utt, eos)
                 seen += bool(want)
     assert seen > 0
+
+
+@pytest.mark.parametrize("name", LM_CASES)
+def test_shallow_fusion_tokens(name):
+    """The oracle's decode / decode_v2 with a language model (decoder.py:93-96, :180-183) against what the reference
+    returned with the same LM (tests/golden/lm, oracle/make_golden_lm.py): widths 1 and 3 of decode, width 3 of
+    decode_v2, log_softmax scoring, lm_weight 0.7, every eos id; and the LM does change some of the answers."""
+    z, hp = load_case(name)
+    g, lm, lm_weight = load_lm(name)
+    m = R.AttModel(hp)
+    m.load_state_dict(params_of(z))
+    m.eval()
+    x = torch.from_numpy(z["x"])
+    lengths = torch.from_numpy(z["lengths"])
+    hp.max_decoder_seq_len, hp.lm_weight, hp.score_func = int(g["max_len"]), lm_weight, "log_softmax"
+    seen = changed = 0
+    for tag, fn, width in LM_RUNS:
+        hp.beam_width = width
+        for utt in range(2):
+            table = g[f"{tag}.utt{utt}"]
+            for eos in range(hp.num_classes):
+                hp.eos_id = eos
+                want = [int(v) for v in table[eos] if v >= 0]
+                got = getattr(m, fn)(x[utt:utt + 1], lengths[utt:utt + 1], lm, None)
+                assert got == want, (tag, utt, eos)
+                seen += bool(want)
+                changed += got != getattr(m, fn)(x[utt:utt + 1], lengths[utt:utt + 1], None, None)
+    assert seen > 0 and changed > 0
+    hp.score_func = "softmax"           # broken in the reference (decoder.py:101-106, :188-193): refused
+    with pytest.raises(ValueError):
+        m.decode(x[:1], lengths[:1], lm, None)
 
 
 def test_beam_v2_rejects_unequal_widths():
