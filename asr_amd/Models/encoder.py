@@ -441,6 +441,11 @@ class Encoder(nn.Module):
     def __init__(self, hp):
         super().__init__()
         self.hp = hp
+        if getattr(hp, "encoder_type", None) == "CNN" and hp.frame_stacking <= 1:
+            # Models/encoder.py:18-22: without frame stacking this selects the VGG front-end (CNN_embedding :38-62),
+            # which SURVEY.md section 2 row 13 leaves outside the path -- refuse instead of silently building a plain BLSTM
+            raise NotImplementedError("asr_amd.Encoder: encoder_type='CNN' (the VGG front-end of Models/encoder.py:38-62) "
+                                      "is outside the accelerated path")
         self.num_layers = hp.num_encoder_layer
         self.hidden = hp.num_hidden_nodes_encoder
         self.dropout = float(hp.encoder_dropout)

@@ -77,6 +77,9 @@ def test_no_cpu_fallback():
         label_smoothing_loss(torch.zeros(1, 2, 5), torch.zeros(1, 2, dtype=torch.long), torch.tensor([2]))
     with pytest.raises(NotImplementedError):
         AttModel(R.make_hp(encoder_type="Wave"))
+    with pytest.raises(NotImplementedError):      # Models/encoder.py:20-22: the VGG front-end, chosen only without frame stacking
+        AttModel(R.make_hp(encoder_type="CNN", frame_stacking=1, num_hidden_nodes=8, num_encoder_layer=1, lmfb_dim=4))
+    AttModel(R.make_hp(encoder_type="CNN", frame_stacking=3, num_hidden_nodes=8, num_encoder_layer=1, lmfb_dim=4))   # :18-19
     # the Conformer branch (Models/AttModel.py:16-17): same module tree as the reference, no CPU path
     from asr_amd.Models.Transformer_encoder import TransformerEncoder
     enc = TransformerEncoder(20, 16, 1, 2, 0.0)
