@@ -957,32 +957,20 @@ __global__ __launch_bounds__(PD_THREADS) void attdec_fwd_persist_kernel(PDParams
                 for (int g = 0; g < 4; ++g) eb[g] = a.Emb[y * 4 * Hd + g * Hd + oj] + a.b_gs[g * Hd + oj];
             }
         }
-        // ---- A. this utterance's state projection (edge P), the alignment window of the convolution
+        // ---- A. the alignment window of the convolution, the conv features (they need the previous step's alignment
+        // only, which this workgroup has had since its own softmax: done BEFORE the wait, in its shadow), then this
+        // utterance's state projection (edge P)
         if (nrows > 0) {
             const int tid = pd_opaque((int)threadIdx.x);
-            if (s > 0 && (tid >> 6) * 256 < A) {          // wave-uniform: waves that hold a granule
-                const int off[1] = {4 * tid < A ? ((pslot * B + b) * A16 + 4 * tid) * 4 : PD_OOB};
-                float4 v[1];
-                pd_gather<1>(v, rX, off, pep, PD_OOB, s_abort, p.err);
-                if (4 * tid < A) {
-                    float *d = m.wfe + 4 * tid * 12 + 10;
-                    d[0] = v[0].x * K2L; d[12] = v[0].y * K2L; d[24] = v[0].z * K2L; d[36] = v[0].w * K2L;
-                }
-            }
             for (int i = tid; i < TT + KW; i += PD_THREADS) {
                 const int t = t0 - PADW + i;
                 m.aw[i] = (t >= 0 && t < T) ? al_prev[t] : 0.f;
             }
         }
         __syncthreads();
-        if (*s_abort) return;
-        PD_STAMP(1);
-        // ---- B. energies of this workgroup's 64 frames
         if (nrows > 0) {
             const int tid = pd_opaque((int)threadIdx.x);
             const int lane = tid & 63, wave = tid >> 6, q = lane >> 4, col = lane & 15, tt = wave & 3, part = wave >> 2;
-            const int tl = 16 * tt + col;
-            const int mt0 = part * PD_MTP;
             {   // conv features as a Toeplitz product, the 25 k-steps of the taps split over the two parts
                 f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};     // two chains: MFMA latency
                 const float *arow = m.aw + 16 * tt + col + q;
@@ -1004,7 +992,25 @@ __global__ __launch_bounds__(PD_THREADS) void attdec_fwd_persist_kernel(PDParams
                     for (int r = 0; r < 4; ++r) m.Fs[part * TT * 12 + (16 * tt + 4 * q + r) * 12 + col] = acc0[r] + acc1[r];
                 }
             }
-            __syncthreads();
+            if (s > 0 && (tid >> 6) * 256 < A) {          // wave-uniform: waves that hold a granule
+                const int off[1] = {4 * tid < A ? ((pslot * B + b) * A16 + 4 * tid) * 4 : PD_OOB};
+                float4 v[1];
+                pd_gather<1>(v, rX, off, pep, PD_OOB, s_abort, p.err);
+                if (4 * tid < A) {
+                    float *d = m.wfe + 4 * tid * 12 + 10;
+                    d[0] = v[0].x * K2L; d[12] = v[0].y * K2L; d[24] = v[0].z * K2L; d[36] = v[0].w * K2L;
+                }
+            }
+        }
+        __syncthreads();
+        if (*s_abort) return;
+        PD_STAMP(1);
+        // ---- B. energies of this workgroup's 64 frames
+        if (nrows > 0) {
+            const int tid = pd_opaque((int)threadIdx.x);
+            const int lane = tid & 63, wave = tid >> 6, q = lane >> 4, col = lane & 15, tt = wave & 3, part = wave >> 2;
+            const int tl = 16 * tt + col;
+            const int mt0 = part * PD_MTP;
             float fB[3];
 #pragma unroll
             for (int ks = 0; ks < 3; ++ks) fB[ks] = m.Fs[tl * 12 + 4 * ks + q] + m.Fs[TT * 12 + tl * 12 + 4 * ks + q];
