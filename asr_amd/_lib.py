@@ -133,6 +133,7 @@ SYMBOLS = {
     "asr_attdec_fwd": (C.c_int, [C.POINTER(AttDecFwdArgs), c_f]),
     "asr_attdec_persist": (C.c_int, [C.c_int]),
     "asr_attdec_debug_stamps": (None, [c_f]),
+    "asr_attdec_pace": (C.c_int, [C.c_int, C.c_int]),
     "asr_attdec_err_offset": (c_i64, [C.c_int] * 5),
     "asr_attdec_greedy": (C.c_int, [C.POINTER(AttDecFwdArgs), c_f, c_f, c_f, c_f, c_f, c_f, c_f]),
     "asr_attdec_step_att": (C.c_int, [C.POINTER(AttDecFwdArgs), c_f, c_f]),

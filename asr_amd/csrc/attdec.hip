@@ -756,6 +756,7 @@ static bool al16(const void *p) { return (((uintptr_t)p) & 15) == 0; }
 #define PD_KF 5            // float4 per lane of a job's K slot: K <= 32 slots x 20 = 640
 // in-launch waits are bounded by wall time: asr_wait_expired (common.h), 4 s on the 100 MHz counter
 #define PD_OOB 0x7ffffff0
+#define PD_NPACE 8
 typedef unsigned int pd_u32x4 __attribute__((ext_vector_type(4)));
 
 struct PDParams {
@@ -766,7 +767,14 @@ struct PDParams {
     int NTILE, EC, NJ, NSP, MTB, nfg, A16, Tp, Tal;
     int o_e, o_g, o_S, xch_bytes;
     unsigned long long *stamps;   // diagnostics only (asr_attdec_debug_stamps): [workgroup][step][PD_NSTAMP] 100 MHz clock
+    int pace[PD_NPACE];           // pause before the first gather attempt of each wait (asr_attdec_pace), units of 256 cycles
 };
+// A wait that starts polling long before its data can be there does harm: every poll of a few hundred workgroups is
+// fabric traffic in front of the very stores being waited for.  pd_pause holds the wave off the memory system for
+// about the time the producer still needs (s_sleep 4 = 256 cycles per unit).
+__device__ __forceinline__ void pd_pause(int n) {
+    for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(4);
+}
 #define PD_NSTAMP 10
 #define PD_STAMP(i)                                                                                   \
     do {                                                                                              \
@@ -797,13 +805,16 @@ __device__ __forceinline__ bool pd_tags_ok(const float4 &v, unsigned e) {
 // hundreds of workgroups re-reading their whole 20-40 KB operand every spin kept the fabric busy enough to delay
 // the very stores they wait for.  The probe is only a hint: the full gather checks every tag and retries.
 // On a timeout sets the abort word and the sticky error.
-template <int NF>
+// PROBE = false (call sites that pass PD_OOB for every lane): no probe stage at all -- even a probe at PD_OOB is a
+// load the wave has to wait for, and loads return in order, so it put everything issued before it (a job's weight
+// rows) in front of the first gather.
+template <int NF, bool PROBE = true>
 __device__ __forceinline__ void pd_gather(float4 (&v)[NF], __amdgpu_buffer_rsrc_t r, const int (&off)[NF], unsigned want,
                                           int probe, int *s_abort, unsigned *err) {
     int spins = 0;
     unsigned long long t0 = 0;
     bool late = false;
-    for (;; ++spins) {
+    for (; PROBE; ++spins) {
         const float4 t = pd_ld4_sc1(r, probe);
         if (__all(pd_tags_ok(t, want) | (probe == PD_OOB))) break;
         if (asr_wait_expired(spins, t0)) {
@@ -995,7 +1006,8 @@ __global__ __launch_bounds__(PD_THREADS) void attdec_fwd_persist_kernel(PDParams
             if (s > 0 && (tid >> 6) * 256 < A) {          // wave-uniform: waves that hold a granule
                 const int off[1] = {4 * tid < A ? ((pslot * B + b) * A16 + 4 * tid) * 4 : PD_OOB};
                 float4 v[1];
-                pd_gather<1>(v, rX, off, pep, PD_OOB, s_abort, p.err);
+                pd_pause(p.pace[0]);
+                pd_gather<1, false>(v, rX, off, pep, PD_OOB, s_abort, p.err);
                 if (4 * tid < A) {
                     float *d = m.wfe + 4 * tid * 12 + 10;
                     d[0] = v[0].x * K2L; d[12] = v[0].y * K2L; d[24] = v[0].z * K2L; d[36] = v[0].w * K2L;
@@ -1100,7 +1112,8 @@ __global__ __launch_bounds__(PD_THREADS) void attdec_fwd_persist_kernel(PDParams
             if (wave * 64 < ng) {      // wave-uniform
                 const int off[1] = {tid < ng ? (p.o_e + (slot * B + b) * Tp + 4 * tid) * 4 : PD_OOB};
                 float4 v[1];
-                pd_gather<1>(v, rX, off, ep, PD_OOB, s_abort, p.err);
+                pd_pause(p.pace[1]);
+                pd_gather<1, false>(v, rX, off, ep, PD_OOB, s_abort, p.err);
                 if (tid < ng) {
                     ev.x = v[0].x;
                     if (4 * tid + 1 < len) ev.y = v[0].y;
@@ -1188,7 +1201,8 @@ __global__ __launch_bounds__(PD_THREADS) void attdec_fwd_persist_kernel(PDParams
                 off[f] = (jrow < B && kbE + 4 * f < keE) ? (p.o_g + slot * B * E + ((kbE >> 2) + f) * 4 * B + 4 * jrow) * 4 : PD_OOB;
             float4 av[PD_KF];
             // no probe: the other producers finish with this workgroup's own context chunk, the wait is a spin or two
-            pd_gather<PD_KF>(av, rX, off, ep, PD_OOB, s_abort, p.err);
+            pd_pause(p.pace[2]);
+            pd_gather<PD_KF, false>(av, rX, off, ep, PD_OOB, s_abort, p.err);
             PD_STAMP(5);
             Tile16Acc acc;
             tile16_init(acc);
@@ -1248,6 +1262,7 @@ __global__ __launch_bounds__(PD_THREADS) void attdec_fwd_persist_kernel(PDParams
                 off[f] = (jrow < B && kbH + 4 * f < keH) ? (p.o_S + slot * B * Hd + ((kbH >> 2) + f) * 4 * B + 4 * jrow) * 4 : PD_OOB;
             float4 av[KFH];
             // probe: lanes 0..2 of each k-slot look at one granule of each of the slot's producers
+            pd_pause(p.pace[cellmode ? 4 : 3]);
             pd_gather<KFH>(av, rX, off, ep, ji == 0 ? off[0] : (ji == 1 ? off[1] : (ji == 2 ? off[2] : PD_OOB)), s_abort, p.err);
             Tile16Acc acc;
             tile16_init(acc);
@@ -1319,6 +1334,19 @@ extern "C" int64_t asr_attdec_err_offset(int B, int T, int E, int Hd, int L) {
 // time stamps (tools/dec_stamps.py); NULL switches it off.  Never set by the product path.
 static unsigned long long *g_attdec_stamps = nullptr;
 extern "C" void asr_attdec_debug_stamps(void *buf) { g_attdec_stamps = static_cast<unsigned long long *>(buf); }
+// pauses in front of the loop kernels' waits, units of 256 cycles: forward 0 = state projection (phase A), 1 = energies
+// (C), 2 = context (D), 3 / 4 = state for the projection job / the cell job's W_ss term (E); backward 8.. (see there).
+// asr_attdec_pace(which, units) sets one (timing experiments, tools/dec_pace.py) and returns the old value; units < 0 only reads.
+// Defaults from tools/dec_pace.py at BASELINE configs 2, 4 and 5: only the waits that re-read a whole operand per attempt
+// respond -- the cell job's context gather (160 workgroups x 40 KB per attempt: 2.03 -> 1.81 ms per forward pass at
+// config 2, 6.15 -> 5.63 at config 4, optimum 12 units = 1.7 us at both, 15 at config 5) and the backward's first two.
+static int g_pd_pace[2 * PD_NPACE] = {0, 0, 12, 0, 0, 0, 0, 0, 12, 4, 0, 0, 0, 0, 0, 0};
+extern "C" int asr_attdec_pace(int which, int units) {
+    if (which < 0 || which >= 2 * PD_NPACE) return -1;
+    const int old = g_pd_pace[which];
+    if (units >= 0) g_pd_pace[which] = units > 4096 ? 4096 : units;
+    return old;
+}
 
 static int g_attdec_persist = -1;           // asr_attdec_persist(0) selects the one-launch-per-kernel loop (A/B, tests)
 static int attdec_persist_on() {
@@ -1465,6 +1493,7 @@ static int run_attdec_fwd(const asr_attdec_fwd_args *a, const GreedyParams *gp, 
             p.xch_bytes = (int)(xfl * 4);
             p.err = reinterpret_cast<unsigned *>(a->ws + asr_attdec_err_offset(B, T, E, Hd, L));
             p.stamps = g_attdec_stamps;
+            for (int i = 0; i < PD_NPACE; ++i) p.pace[i] = g_pd_pace[i];
             // every exchanged float starts with the "wrong" epoch tag (LSB = 1)
             attdec_init(a->S, BH, a->C, BH, a->sproj, BA, err_word, p.xch, xfl, st);
             inited = true;
@@ -2309,6 +2338,7 @@ struct PBParams {
     int NTILE, MTB, NJX, NJG, ECG, ECH, A16, Tp;
     int o_drec, o_dgp, o_dot, o_dspp, o_dF, xch_bytes;
     unsigned long long *stamps;
+    int pace[PD_NPACE];           // as PDParams.pace: pauses before the waits, in source order (asr_attdec_pace 8..15)
 };
 #define PB_XW (163 * 12)          // flattened dF window: frames t0 - 49 .. t0 + 113, 12 floats each
 #define PB_KF (1200 + 2 * 180)    // flattened reversed taps, 180 zeros either side
@@ -2468,7 +2498,8 @@ __global__ __launch_bounds__(PD_THREADS) void attdec_bwd_persist_kernel(PBParams
                                   ? (p.o_drec + slot * NGR_R * 4 * B + (((c * KH + kb) >> 2) + fq) * 4 * B + 4 * jrow) * 4
                                   : PD_OOB;
                 float4 av[PD_KF];
-                pd_gather<PD_KF>(av, rX, off, ep, PD_OOB, s_abort, p.err);   // published by now or within a spin or two: no probe
+                pd_pause(p.pace[0]);
+                pd_gather<PD_KF, false>(av, rX, off, ep, PD_OOB, s_abort, p.err);   // published by now or within a spin or two: no probe
 #pragma unroll
                 for (int fq = 0; fq < PD_KF; ++fq) {
                     acc.a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[fq].x, wv[fq].x, acc.a0, 0, 0, 0);
@@ -2515,6 +2546,7 @@ __global__ __launch_bounds__(PD_THREADS) void attdec_bwd_persist_kernel(PBParams
                     off[fq] = (jrow < B && kb + 4 * fq < ke)
                                   ? (pslot * NGR_A * 4 * B + ((kb >> 2) + fq) * 4 * B + 4 * jrow) * 4 : PD_OOB;
                 float4 av[PD_KF];
+                pd_pause(p.pace[1]);
                 pd_gather<PD_KF>(av, rX, off, pep, off[0], s_abort, p.err);
                 PD_STAMP(1);
                 Tile16Acc acc;
@@ -2563,7 +2595,8 @@ __global__ __launch_bounds__(PD_THREADS) void attdec_bwd_persist_kernel(PBParams
                 const int lane = pd_opaque((int)threadIdx.x) & 63;
                 const int off[1] = {lane < nact ? (p.o_dot + ((slot * B + b) * NTILE + lane) * 4) * 4 : PD_OOB};
                 float4 dv[1];
-                pd_gather<1>(dv, rX, off, ep, PD_OOB, s_abort, p.err);
+                pd_pause(p.pace[2]);
+                pd_gather<1, false>(dv, rX, off, ep, PD_OOB, s_abort, p.err);
             }
             __syncthreads();
             if (*s_abort) return;
@@ -2589,7 +2622,8 @@ __global__ __launch_bounds__(PD_THREADS) void attdec_bwd_persist_kernel(PBParams
                     const int t = t0 - (KW - 1 - PADW) + r;
                     const bool ok = tid < 163 * 3 && t >= 0 && t < len;
                     const int off[1] = {ok ? (p.o_dF + ((pslot * B + b) * Tp + t) * 12 + 4 * gq) * 4 : PD_OOB};
-                    pd_gather<1>(xv, rX, off, pep, PD_OOB, s_abort, p.err);
+                    pd_pause(p.pace[3]);
+                    pd_gather<1, false>(xv, rX, off, pep, PD_OOB, s_abort, p.err);
                 }
                 if (tid < TT) altile[tid] = alv;
 #pragma unroll
@@ -2656,6 +2690,7 @@ __global__ __launch_bounds__(PD_THREADS) void attdec_bwd_persist_kernel(PBParams
                 off[fq] = (jrow < B && kb + 4 * fq < ke)
                               ? (p.o_drec + slot * NGR_R * 4 * B + (((gh * KH + kb) >> 2) + fq) * 4 * B + 4 * jrow) * 4 : PD_OOB;
             float4 av[PD_KF];
+            pd_pause(p.pace[4]);
             pd_gather<PD_KF>(av, rX, off, ep, off[0], s_abort, p.err);
             PD_STAMP(3);
             Tile16Acc acc;
@@ -2694,7 +2729,8 @@ __global__ __launch_bounds__(PD_THREADS) void attdec_bwd_persist_kernel(PBParams
                     const int off[2] = {act ? (p.o_dgp + ((slot * 2 + 0) * B + b) * E + 4 * tid) * 4 : PD_OOB,
                                         act ? (p.o_dgp + ((slot * 2 + 1) * B + b) * E + 4 * tid) * 4 : PD_OOB};
                     float4 v[2];
-                    pd_gather<2>(v, rX, off, ep, PD_OOB, s_abort, p.err);
+                    pd_pause(p.pace[5]);
+                    pd_gather<2, false>(v, rX, off, ep, PD_OOB, s_abort, p.err);
                     if (act) {
                         const float4 d4 = make_float4(v[0].x + v[1].x, v[0].y + v[1].y, v[0].z + v[1].z, v[0].w + v[1].w);
                         *reinterpret_cast<float4 *>(dgs + 4 * tid) = d4;
@@ -2724,7 +2760,8 @@ __global__ __launch_bounds__(PD_THREADS) void attdec_bwd_persist_kernel(PBParams
                     if (lane == 0) pd_st4_tag(rX, (p.o_dot + ((slot * B + b) * NTILE + k) * 4) * 4, make_float4(v, 0.f, 0.f, 0.f), ep);
                     const int off[1] = {lane < nact ? (p.o_dot + ((slot * B + b) * NTILE + lane) * 4) * 4 : PD_OOB};
                     float4 dv[1];
-                    pd_gather<1>(dv, rX, off, ep, PD_OOB, s_abort, p.err);
+                    pd_pause(p.pace[6]);
+                    pd_gather<1, false>(dv, rX, off, ep, PD_OOB, s_abort, p.err);
                     const float d = wave_sum(lane < nact ? dv[0].x : 0.f);
                     if (lane == 0) *sdot = d;
                 }
@@ -2854,7 +2891,8 @@ __global__ __launch_bounds__(PD_THREADS) void attdec_bwd_persist_kernel(PBParams
                 const bool act = kk < nact && colA < A;
                 const int off[1] = {act ? (p.o_dspp + ((slot * B + b) * NTILE + kk) * A16 + colA) * 4 : PD_OOB};
                 float4 v[1];
-                pd_gather<1>(v, rX, off, ep, PD_OOB, s_abort, p.err);
+                pd_pause(p.pace[7]);
+                pd_gather<1, false>(v, rX, off, ep, PD_OOB, s_abort, p.err);
                 if (kk < nact) *reinterpret_cast<float4 *>(rbuf + kk * ECH + 4 * g4) = act ? v[0] : zero4();
             }
             __syncthreads();
@@ -3047,6 +3085,7 @@ extern "C" int asr_attdec_bwd(const asr_attdec_bwd_args *a, void *stream) {
             p.xch_bytes = (int)(xfl * 4);
             p.err = reinterpret_cast<unsigned *>(a->ws + asr_attdec_bwd_err_offset(B, T, E, Hd, L));
             p.stamps = g_attdec_stamps;
+            for (int i = 0; i < PD_NPACE; ++i) p.pace[i] = g_pd_pace[PD_NPACE + i];
             attdec_init(dC, BH, a->dsp, BA, nullptr, 0, err_word, p.xch, xfl, st);
             inited = true;
             if (p.stamps) hipLaunchKernelGGL(attdec_bwd_persist_kernel<true>, dim3((unsigned)nwg), dim3(PD_THREADS), psm, st, p);

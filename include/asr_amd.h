@@ -518,6 +518,12 @@ int asr_attdec_persist(int on);
 int asr_attdec_plan(int B, int T, int E, int Hd, int L);
 /* diagnostics (tools/dec_stamps.py): device buffer for per-phase time stamps of the persistent launches, NULL = off */
 void asr_attdec_debug_stamps(void *buf);
+/* Pauses in front of the loop kernels' in-launch waits, in units of 256 cycles (a wave that starts polling long before
+ * its data can be there only adds fabric traffic in front of the stores it waits for): which = 0..4 forward (state
+ * projection, energies, context, state for the projection job, state for the cell job), 8.. backward.  Sets one and
+ * returns the previous value; units < 0 only reads.  The defaults are tuned at the BASELINE shapes
+ * (tools/dec_pace.py); results do not depend on them.  No counterpart in the reference. */
+int asr_attdec_pace(int which, int units);
 int64_t asr_attdec_err_offset(int B, int T, int E, int Hd, int L);
 
 /* Greedy search, batch 1: the beam_width == 1 path of Models/decoder.py:63-130.
