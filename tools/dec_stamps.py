@@ -6,6 +6,9 @@ from asr_amd import _lib
 from asr_amd.Models.decoder import Decoder
 from bench import make_hp
 lib = _lib.load()
+for kv in os.environ.get("DEC_PACE", "").split():          # DEC_PACE="5=1 3=36": asr_attdec_pace settings for this run
+    k, v = kv.split("=")
+    lib.asr_attdec_pace(int(k), int(v))
 dev = torch.device("cuda:0")
 hp = make_hp()
 torch.manual_seed(0)
