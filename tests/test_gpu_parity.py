@@ -896,6 +896,48 @@ def test_golden_beam_v2_tokens(name):
         assert m.decode_v2(x[0:1].to(dev), lengths[0:1]) == [int(v) for v in table[eos] if v >= 0]
 
 
+def test_decoder_loop_pauses_do_not_change_results():
+    """asr_attdec_pace: the pauses in front of the loop kernels' waits are timing only -- with every pause at 0 and with
+    long ones (3 to 63 units) the outputs and the data gradient are bit-identical to the defaults' (the weight gradients
+    agree to the run-to-run order of their atomic split-K sums), and no wait times out."""
+    from asr_amd import _lib
+    from asr_amd.Models.decoder import Decoder
+    from asr_amd.Models.encoder import persistent_error_flags
+    from oracle import ref_model as R
+    lib = _lib.load()
+    dev = _dev()
+    B, T, He, Hd, V, L = 32, 500, 320, 320, 100, 6
+    assert lib.asr_attdec_plan(B, T, 2 * He, Hd, L) == 3
+    hp = R.make_hp(num_hidden_nodes_encoder=He, num_hidden_nodes_decoder=Hd, num_classes=V)
+    torch.manual_seed(5)
+    dec = Decoder(hp).to(dev).train()
+    lengths = torch.linspace(T, int(0.6 * T), B).long()
+    h = torch.randn(B, T, 2 * He)
+    for b in range(B):
+        h[b, lengths[b]:] = 0
+    tgt, w = torch.randint(0, V, (B, L)).to(dev), torch.randn(B, L, V).to(dev)
+    defaults = [lib.asr_attdec_pace(i, -1) for i in range(16)]
+    assert defaults[2] > 0 and lib.asr_attdec_pace(16, 0) == -1
+    res = []
+    try:
+        for setting in (defaults, [0] * 16, [3 + 4 * i for i in range(16)]):
+            for i, v in enumerate(setting):
+                lib.asr_attdec_pace(i, v)
+            dec.zero_grad(set_to_none=True)
+            hd = h.to(dev).requires_grad_(True)
+            y = dec(hd, lengths, tgt)
+            (y * w).sum().backward()
+            res.append([y.detach().clone(), hd.grad.clone()] + [p.grad.clone() for p in dec.parameters()])
+    finally:
+        for i, v in enumerate(defaults):
+            lib.asr_attdec_pace(i, v)
+    assert not persistent_error_flags()
+    for other in res[1:]:
+        assert torch.equal(res[0][0], other[0]) and torch.equal(res[0][1], other[1])      # youtput, d hbatch
+        for a_, b_ in zip(res[0][2:], other[2:]):       # weight gradients: split-K sums with float atomics, order varies
+            assert rel_err(b_.cpu(), a_.cpu()) < 1e-5
+
+
 def test_beam_v2_errors():
     """The reference raises RuntimeError for unequal encoder/decoder widths (decoder.py:219,241)
     and for widths its topk calls reject; an LM together with softmax scoring is refused."""
