@@ -417,7 +417,7 @@ extern "C" int asr_dwconv_bwd_w(const float *dy, const float *x, float *part, in
 // channel sums: msum (sum of x, from asr_colsum) and vsum (sum of (x - mean)^2, from
 // asr_bn_var_part + asr_colsum) with multipliers ms, vs (1/rows in training; 1 with the running
 // statistics in eval mode), so no statistic ever visits the host.
-#define BN_ROWS 256
+#define BN_ROWS 32       // rows per block of the partial-sum kernels: 8 per wave, all their loads in flight at once
 __global__ __launch_bounds__(256) void bn_var_part_kernel(const float *__restrict__ x, const float *__restrict__ msum,
                                                           float ms, float *__restrict__ part, int64_t rows, int C) {
     __shared__ float red[4][64];
@@ -427,8 +427,15 @@ __global__ __launch_bounds__(256) void bn_var_part_kernel(const float *__restric
     float acc = 0.f;
     if (c < C) {
         const float mu = msum[c] * ms;
-        for (int64_t r = r0 + w; r < min(rows, r0 + BN_ROWS); r += 4) {
-            const float t = x[r * C + c] - mu;
+        float xv[BN_ROWS / 4];
+#pragma unroll
+        for (int k = 0; k < BN_ROWS / 4; ++k) {       // branch-free: rows past the end re-read row r0 and count as zero
+            const int64_t r = r0 + w + 4 * k;
+            xv[k] = x[(r < rows ? r : r0) * C + c];
+        }
+#pragma unroll
+        for (int k = 0; k < BN_ROWS / 4; ++k) {
+            const float t = r0 + w + 4 * k < rows ? xv[k] - mu : 0.f;
             acc += t * t;
         }
     }
@@ -459,9 +466,17 @@ __global__ __launch_bounds__(256) void bn_swish_bwd_part_kernel(const float *__r
     float a0 = 0.f, a1 = 0.f;
     if (c < C) {
         const float mu = msum[c] * ms, rs = rsqrtf(vsum[c] * vs + eps), gc = g[c], bc = b[c];
-        for (int64_t r = r0 + w; r < min(rows, r0 + BN_ROWS); r += 4) {
-            const float xh = (x[r * C + c] - mu) * rs, u = xh * gc + bc, s = sigmoid_exact(u);
-            const float du = dy[r * C + c] * s * (1.f + u * (1.f - s));
+        float xv[BN_ROWS / 4], dv[BN_ROWS / 4];
+#pragma unroll
+        for (int k = 0; k < BN_ROWS / 4; ++k) {       // branch-free, as above: 16 loads in flight per lane
+            const int64_t r = r0 + w + 4 * k, rr = r < rows ? r : r0;
+            xv[k] = x[rr * C + c];
+            dv[k] = dy[rr * C + c];
+        }
+#pragma unroll
+        for (int k = 0; k < BN_ROWS / 4; ++k) {
+            const float xh = (xv[k] - mu) * rs, u = xh * gc + bc, s = sigmoid_exact(u);
+            const float du = r0 + w + 4 * k < rows ? dv[k] * s * (1.f + u * (1.f - s)) : 0.f;
             a0 += du;
             a1 += du * xh;
         }
