@@ -449,3 +449,24 @@ def test_weight_gradients_on_side_stream_match_one_stream():
                 assert float((g1[n] - g0[n]).abs().max()) <= 1e-5 * float(g0[n].abs().max()) + 1e-12, n
     finally:
         streams.enable(was)
+
+
+@pytest.mark.parametrize("n", [1, 10, 4096, 4100, 3 * 11968 * 64])
+@pytest.mark.parametrize("masked", [False, True])
+def test_scale_mask_scalar_and_16_byte_paths(n, masked):
+    """asr_scale_mask (a block's output dropout backward): the 16-byte kernel (n % 4 == 0, aligned) and the scalar one,
+    with and without a mask, bit for bit against torch; a misaligned view falls back to the scalar kernel."""
+    import ctypes as C
+    from asr_amd import _lib
+    lib = _lib.load()
+    dev = _dev()
+    g = torch.Generator().manual_seed(n)
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    for shift in (0, 1):                                        # shift 1: pointers 4 bytes off a 16-byte boundary
+        dy = torch.randn(n + shift, generator=g).to(dev)[shift:]
+        mask = (torch.rand(n + shift, generator=g) < 0.7).to(torch.uint8).to(dev)[shift:] if masked else None
+        out = torch.full((n + shift,), 7.0, device=dev)[shift:]
+        assert lib.asr_scale_mask(dy.data_ptr(), mask.data_ptr() if masked else 0, out.data_ptr(), n, C.c_float(1.25), st) == 0
+        want = dy * 1.25 * (mask.float() if masked else 1.0)
+        assert torch.equal(out, want)
+
