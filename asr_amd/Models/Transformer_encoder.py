@@ -73,7 +73,9 @@ def _ln_fwd(x2, g, b):
 
 
 def _ln_bwd(dy2, x2, g, mean, rstd, res):
-    """Returns (res + d LayerNorm / dx, d gamma, d beta); ``res`` = the gradient over the residual connection."""
+    """Returns (res + d LayerNorm / dx, per-block partials of [d gamma | d beta]); ``res`` = the gradient over the
+    residual connection.  The partials are summed by _ln_bwd_sums inside the caller's side-stream block: nothing
+    downstream reads d gamma / d beta, and the two launches of the sum were 64 times per step on the chain."""
     lib = _lib.load()
     rows, d = x2.shape
     nb = int(lib.asr_layernorm_bwd_blocks(rows))
@@ -81,9 +83,14 @@ def _ln_bwd(dy2, x2, g, mean, rstd, res):
     dx = torch.empty_like(x2)
     check(lib.asr_layernorm_bwd(dy2.data_ptr(), x2.data_ptr(), g.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
                                 dx.data_ptr(), part.data_ptr(), rows, d, res.data_ptr(), _st()))
-    gb = _e(2 * d, like=x2)
+    return dx, part
+
+
+def _ln_bwd_sums(part):
+    d = part.shape[1] // 2
+    gb = _e(2 * d, like=part)
     ops.colsum(part, gb)
-    return dx, gb[:d], gb[d:]
+    return gb[:d], gb[d:]
 
 
 def _residual_drop(x2, o, factor, p, training, ndrop):
@@ -202,7 +209,7 @@ class _FFFunction(torch.autograd.Function):
         y, m_o, f = _residual_drop(x2, o, scale, p, training, n_out_drop)
         ctx.save_for_backward(x2, ln_w, w1, w2, mean, rstd, h, a, s)
         ctx.aux = (p, m1, m_o, f)
-        ctx.wparams = (w1, b1, w2, b2)
+        ctx.wparams = (w1, b1, w2, b2, ln_w, ln_b)
         return y.view_as(x)
 
     @staticmethod
@@ -218,9 +225,10 @@ class _FFFunction(torch.autograd.Function):
         check(lib.asr_swish_bwd(ds.data_ptr(), a.data_ptr(), m1.data_ptr() if m1 is not None else 0, da.data_ptr(),
                                 a.numel(), C.c_float(p if m1 is not None else 0.0), _st()))
         dh = _linear_dx(da, w1)
-        dx, dg, dbeta = _ln_bwd(dh, x2, ln_w, mean, rstd, dy2)
-        with streams.on_side(dy2.device, do, s, da, h, params=ctx.wparams):
+        dx, lnpart = _ln_bwd(dh, x2, ln_w, mean, rstd, dy2)
+        with streams.on_side(dy2.device, do, s, da, h, lnpart, params=ctx.wparams):
             (dW2, dW1), (db2, db1) = _linear_dw([(do, s, w2), (da, h, w1)], [(do, w2.shape[0]), (da, w1.shape[0])])
+            dg, dbeta = _ln_bwd_sums(lnpart)
         return dx.view_as(dy), dg, dbeta, dW1, db1, dW2, db2, None, None, None, None
 
 
@@ -274,7 +282,7 @@ class _RelAttnFunction(torch.autograd.Function):
         y, m_o, f_o = _residual_drop(x2, _linear(cx, wo, bo), 1.0, p, training, 1)
         ctx.save_for_backward(x2, nw, wq, wk, wv, wpos, wo, pe, keep, mean, rstd, h, qu, qv, k, vv, pp, attn, attn_d, cx)
         ctx.aux = (B, T, d, H, p, scale, m_att, m_o, f_o)
-        ctx.wparams = (wq, bq, wk, bk, wv, bv, wpos, u, v, wo, bo)
+        ctx.wparams = (wq, bq, wk, bk, wv, bv, wpos, u, v, wo, bo, nw, nb_)
         return y.view_as(x)
 
     @staticmethod
@@ -305,8 +313,9 @@ class _RelAttnFunction(torch.autograd.Function):
         dh = _linear_dx(dq, wq)
         _linear_dx(dkk, wk, dx_out=dh, accumulate=True)
         _linear_dx(dvv, wv, dx_out=dh, accumulate=True)
-        dx, dg, dbeta = _ln_bwd(dh, x2, nw, mean, rstd, dy2)
-        with streams.on_side(dy2.device, do, cx, dq, dkk, dvv, h, dbd, qv, pe, dqu, dqv, params=ctx.wparams):
+        dx, lnpart = _ln_bwd(dh, x2, nw, mean, rstd, dy2)
+        with streams.on_side(dy2.device, do, cx, dq, dkk, dvv, h, dbd, qv, pe, dqu, dqv, lnpart, params=ctx.wparams):
+            dg, dbeta = _ln_bwd_sums(lnpart)
             # d p[h] = sum_b d bd[b,h]^T (q + v)[b,:,h,:]: the reduction runs over (b, i) through a two-level row map
             # (only heads x ceil(T/64) tiles: split the long reduction over workgroups, 464 -> 52 us at config 5)
             sk = max(1, min(16, (B * T) // 512))
@@ -358,7 +367,7 @@ class _ConvModuleFunction(torch.autograd.Function):
         y, m_o, f_o = _residual_drop(x2, _linear(s, W2, pw2b), 1.0, p, training, 1)
         ctx.save_for_backward(x2, lnw, pw1w, dww, cow, bnw, bnb, pw2w, mean, rstd, h, a, g, c1, c2, msum, vsum, s)
         ctx.aux = (B, T, d, p, training, ms, vs, m_o, f_o)
-        ctx.wparams = (pw1w, pw1b, dww, dwb, cow, cob, pw2w, pw2b)
+        ctx.wparams = (pw1w, pw1b, dww, dwb, cow, cob, pw2w, pw2b, lnw, lnb)
         return y.view_as(x)
 
     @staticmethod
@@ -387,8 +396,9 @@ class _ConvModuleFunction(torch.autograd.Function):
         da = torch.empty_like(a)
         check(lib.asr_glu_bwd(dg.data_ptr(), a.data_ptr(), da.data_ptr(), rows, d, _st()))
         dh = _linear_dx(da, W1)
-        dx, dgam, dbeta = _ln_bwd(dh, x2, lnw, mean, rstd, dy2)
-        with streams.on_side(dy2.device, do, s, dc2, c1, dc1, g, da, h, params=ctx.wparams):
+        dx, lnpart = _ln_bwd(dh, x2, lnw, mean, rstd, dy2)
+        with streams.on_side(dy2.device, do, s, dc2, c1, dc1, g, da, h, lnpart, params=ctx.wparams):
+            dgam, dbeta = _ln_bwd_sums(lnpart)
             wpart = _e(int(lib.asr_dwconv_bwd_w_chunks(B, T)), KSIZE * d, like=x2)
             check(lib.asr_dwconv_bwd_w(dc1.data_ptr(), g.data_ptr(), wpart.data_ptr(), B, T, d, KSIZE, _st()))
             dwkc = _e(KSIZE, d, like=x2)
