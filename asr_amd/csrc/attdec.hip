@@ -1339,8 +1339,10 @@ extern "C" void asr_attdec_debug_stamps(void *buf) { g_attdec_stamps = static_ca
 // asr_attdec_pace(which, units) sets one (timing experiments, tools/dec_pace.py) and returns the old value; units < 0 only reads.
 // Defaults from tools/dec_pace.py at BASELINE configs 2, 4 and 5: only the waits that re-read a whole operand per attempt
 // respond -- the cell job's context gather (160 workgroups x 40 KB per attempt: 2.03 -> 1.81 ms per forward pass at
-// config 2, 6.15 -> 5.63 at config 4, optimum 12 units = 1.7 us at both, 15 at config 5) and the backward's first two.
-static int g_pd_pace[2 * PD_NPACE] = {0, 0, 12, 0, 0, 0, 0, 0, 12, 4, 0, 0, 0, 0, 0, 0};
+// config 2, 6.15 -> 5.63 at config 4, optimum 12 units = 1.7 us at both, 15 at config 5) and, a little, the backward's
+// second wait (4 units: -0.04 ms at configs 2 and 4).  The backward's first wait gains 0.015 ms at config 2 with 12
+// units but loses 0.28 ms at config 4 and 0.17 at config 5: left at 0.
+static int g_pd_pace[2 * PD_NPACE] = {0, 0, 12, 0, 0, 0, 0, 0, 0, 4, 0, 0, 0, 0, 0, 0};
 extern "C" int asr_attdec_pace(int which, int units) {
     if (which < 0 || which >= 2 * PD_NPACE) return -1;
     const int old = g_pd_pace[which];
