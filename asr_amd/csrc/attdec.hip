@@ -808,9 +808,10 @@ __device__ __forceinline__ bool pd_tags_ok(const float4 &v, unsigned e) {
 // PROBE = false (call sites that pass PD_OOB for every lane): no probe stage at all -- even a probe at PD_OOB is a
 // load the wave has to wait for, and loads return in order, so it put everything issued before it (a job's weight
 // rows) in front of the first gather.
+// Returns the number of full-gather attempts that failed (0 = the first one found everything).
 template <int NF, bool PROBE = true>
-__device__ __forceinline__ void pd_gather(float4 (&v)[NF], __amdgpu_buffer_rsrc_t r, const int (&off)[NF], unsigned want,
-                                          int probe, int *s_abort, unsigned *err) {
+__device__ __forceinline__ int pd_gather(float4 (&v)[NF], __amdgpu_buffer_rsrc_t r, const int (&off)[NF], unsigned want,
+                                         int probe, int *s_abort, unsigned *err) {
     int spins = 0;
     unsigned long long t0 = 0;
     bool late = false;
@@ -832,13 +833,13 @@ __device__ __forceinline__ void pd_gather(float4 (&v)[NF], __amdgpu_buffer_rsrc_
         bool ok = true;
 #pragma unroll
         for (int f = 0; f < NF; ++f) ok = ok & (pd_tags_ok(v[f], want) | (off[f] == PD_OOB));
-        if (__all(ok)) return;
+        if (__all(ok)) return spins;
         if (late || asr_wait_expired(spins, t1)) {
             if ((threadIdx.x & 63) == 0) {
                 *s_abort = 1;
                 __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
-            return;
+            return spins;
         }
         __builtin_amdgcn_s_sleep(1);
     }
@@ -947,6 +948,7 @@ __global__ __launch_bounds__(PD_THREADS) void attdec_fwd_persist_kernel(PDParams
     kqE = (kqE + 3) & ~3;
     kqH = (kqH + 3) & ~3;
     float c_reg = 0.f;        // cell state of the owner threads (16 rows x 4 units on threads 0..63)
+    int pace_d = p.pace[2], fails_d = 0;
     __syncthreads();
 
     for (int s = 0; s < L; ++s) {
@@ -1201,8 +1203,14 @@ __global__ __launch_bounds__(PD_THREADS) void attdec_fwd_persist_kernel(PDParams
                 off[f] = (jrow < B && kbE + 4 * f < keE) ? (p.o_g + slot * B * E + ((kbE >> 2) + f) * 4 * B + 4 * jrow) * 4 : PD_OOB;
             float4 av[PD_KF];
             // no probe: the other producers finish with this workgroup's own context chunk, the wait is a spin or two
-            pd_pause(p.pace[2]);
-            pd_gather<PD_KF, false>(av, rX, off, ep, PD_OOB, s_abort, p.err);
+            // paced first attempt (see PDParams.pace): p.pace[2] to start with, then by the wave's own record -- two
+            // steps longer when two or more of the last eight first attempts failed, one shorter when none did
+            pd_pause(pace_d);
+            fails_d += pd_gather<PD_KF, false>(av, rX, off, ep, PD_OOB, s_abort, p.err) > 0;
+            if ((s & 7) == 7) {
+                if (p.pace[5] == 0) pace_d = fails_d >= 2 ? min(pace_d + 2, 64) : (fails_d == 0 ? max(pace_d - 1, 0) : pace_d);
+                fails_d = 0;
+            }
             PD_STAMP(5);
             Tile16Acc acc;
             tile16_init(acc);
@@ -1335,7 +1343,8 @@ extern "C" int64_t asr_attdec_err_offset(int B, int T, int E, int Hd, int L) {
 static unsigned long long *g_attdec_stamps = nullptr;
 extern "C" void asr_attdec_debug_stamps(void *buf) { g_attdec_stamps = static_cast<unsigned long long *>(buf); }
 // pauses in front of the loop kernels' waits, units of 256 cycles: forward 0 = state projection (phase A), 1 = energies
-// (C), 2 = context (D), 3 / 4 = state for the projection job / the cell job's W_ss term (E); backward 8.. (see there).
+// (C), 2 = context (D: the START value, each wave then adapts it to its own record of failed first attempts unless
+// entry 5 is non-zero), 3 / 4 = state for the projection job / the cell job's W_ss term (E); backward 8.. (see there).
 // asr_attdec_pace(which, units) sets one (timing experiments, tools/dec_pace.py) and returns the old value; units < 0 only reads.
 // Defaults from tools/dec_pace.py at BASELINE configs 2, 4 and 5: only the waits that re-read a whole operand per attempt
 // respond -- the cell job's context gather (160 workgroups x 40 KB per attempt: 2.03 -> 1.81 ms per forward pass at

@@ -520,7 +520,8 @@ int asr_attdec_plan(int B, int T, int E, int Hd, int L);
 void asr_attdec_debug_stamps(void *buf);
 /* Pauses in front of the loop kernels' in-launch waits, in units of 256 cycles (a wave that starts polling long before
  * its data can be there only adds fabric traffic in front of the stores it waits for): which = 0..4 forward (state
- * projection, energies, context, state for the projection job, state for the cell job), 8.. backward.  Sets one and
+ * projection, energies, context, state for the projection job, state for the cell job; the context pause is a start
+ * value that every wave adapts to its own failed first attempts unless entry 5 is non-zero), 8.. backward.  Sets one and
  * returns the previous value; units < 0 only reads.  The defaults are tuned at the BASELINE shapes
  * (tools/dec_pace.py); results do not depend on them.  No counterpart in the reference. */
 int asr_attdec_pace(int which, int units);
